@@ -1,0 +1,183 @@
+/* pedoni_hip.h -- C ABI of the MI355X (gfx950) social-force backend.
+ *
+ * This is the drop-in boundary for ONE path of qt2/pedoni: the model plugin
+ * `trait PedestrianModel` (pedoni-simulator/src/models/mod.rs:13-25) as implemented by
+ * the CPU `SocialForceModel` (models/sfm.rs).  A third `Backend` variant in the
+ * reference (lib.rs:32-35,138-142) would own a `PedoniModel*` and forward the five trait
+ * methods to the `pedoni_hip_*` entry points marked [trait] below; INTEGRATION.md shows
+ * that Rust binding.  Everything else here ([ext]) is what the reference's trait cannot
+ * express but a device-resident backend needs: full-state injection/export (the
+ * reference's `list_pedestrians` drops velocity and desired speed, sfm.rs:257-265),
+ * a stream hook, multi-step launches, kernel timing and the ghost-row exchange used
+ * when agents are sharded over several GPUs.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * negative PEDONI_E_* code, and `pedoni_hip_last_error()` describes the last failure
+ * on the calling thread.  The reference's trait has no `Result`: failures panic
+ * (sfm_gpu.rs:127 `.unwrap()`), so a binding should `panic!` on non-zero.  The
+ * library copies every input it keeps; callers own all buffers they pass.  An object
+ * may be created on one thread and used from another (the reference moves the
+ * simulator into a worker thread, pedoni/src/main.rs:79-81): every entry point binds the
+ * model's device first.  No entry point is re-entrant for the same model.
+ *
+ * Arithmetic is fp32 throughout, evaluated in the reference's operation order without
+ * FMA contraction; exp() replays glibc's expf in f64 so that results are bit-identical
+ * to the reference CPU path on a glibc host (math_mode PEDONI_MATH_EXACT).
+ */
+#ifndef PEDONI_HIP_H
+#define PEDONI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PEDONI_OK 0
+#define PEDONI_E_INVALID (-1)  /* bad argument */
+#define PEDONI_E_HIP (-2)      /* HIP runtime error (message has the hipError string) */
+#define PEDONI_E_NO_DEVICE (-3)
+#define PEDONI_E_CAPACITY (-4) /* fixed-capacity buffer too small (halo exchange) */
+
+#define PEDONI_MATH_EXACT 0 /* IEEE div/sqrt + glibc-replay exp: bit parity with the CPU path */
+#define PEDONI_MATH_FAST 1  /* v_rcp/v_rsq/v_exp hardware approximations (<= 1e-5 rel.) */
+
+typedef struct PedoniModel PedoniModel;
+
+/* lib.rs:108-135 `SimulatorOptions` (same defaults) + backend-only knobs. */
+typedef struct {
+    float neighbor_grid_unit;  /* lib.rs:113, default 1.4  */
+    float field_grid_unit;     /* lib.rs:115, default 0.25 (informational: maps carry their unit) */
+    int32_t use_neighbor_grid; /* lib.rs:117, default 1 */
+    int32_t use_distance_map;  /* lib.rs:119, default 1 */
+    int32_t gpu_work_size;     /* lib.rs:121, workgroup size of the force kernel; 0 = library default */
+    int32_t math_mode;         /* PEDONI_MATH_* */
+    uint64_t seed;             /* desired-speed RNG seed (reference: unseeded fastrand, sfm.rs:54) */
+    uint32_t initial_capacity; /* agents to pre-allocate for; arrays grow on demand */
+    uint32_t reserved;
+} PedoniOptions;
+
+/* scenario.rs:23-35 `ObstacleConfig { line: [Vec2; 2], width }` */
+typedef struct { float x0, y0, x1, y1, width; } PedoniObstacle;
+
+/* models/mod.rs:28-32 `Pedestrian { pos: Vec2, destination: usize }` in a fixed C layout */
+typedef struct { float x, y; uint64_t destination; } PedoniPedestrian;
+
+/* diagnostic.rs:45-50 `StepMetrics`; time_calc_state_kernel < 0 means None */
+typedef struct {
+    int32_t active_ped_count;
+    double time_spawn;
+    double time_calc_state;
+    double time_calc_state_kernel;
+} PedoniStepMetrics;
+
+/* per-kernel device time accumulated while profiling is enabled (hipEvent pairs) */
+#define PEDONI_N_KERNELS 8
+typedef struct {
+    double total_ms[PEDONI_N_KERNELS];
+    uint64_t launches[PEDONI_N_KERNELS];
+} PedoniKernelTimes;
+/* indices into PedoniKernelTimes */
+#define PEDONI_K_BIN 0       /* cell key + despawn test + per-cell count   */
+#define PEDONI_K_SCAN 1      /* exclusive scan -> neighbor_grid_indices     */
+#define PEDONI_K_SLOT 2      /* write agent index into its cell's slot range */
+#define PEDONI_K_REORDER 3   /* stable in-cell rank + SoA scatter            */
+#define PEDONI_K_FORCE 4     /* goal + pair + obstacle force + integrator    */
+#define PEDONI_K_HALO_PACK 5
+#define PEDONI_K_HALO_UNPACK 6
+#define PEDONI_K_OTHER 7
+
+const char* pedoni_hip_last_error(void);
+void pedoni_hip_default_options(PedoniOptions* opt);
+int pedoni_hip_device_count(int32_t* n);
+
+/* [trait] PedestrianModel::new (models/mod.rs:14; sfm.rs:36-46).  `size_*` is
+ * scenario.field.size; the maps are `Field.distance_map` / `Field.potential_maps`
+ * (field.rs:194-205), row-major (y, x), `field_rows x field_cols`, sampled at
+ * `field_unit`; obstacles = scenario.obstacles (read only when use_distance_map == 0,
+ * sfm.rs:194).  All inputs are copied to the device. */
+int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
+                      const float* distance_map, const float* const* potential_maps,
+                      uint32_t n_maps, uint32_t field_rows, uint32_t field_cols,
+                      float field_unit, const PedoniObstacle* obstacles, uint32_t n_obstacles,
+                      int device, PedoniModel** out);
+void pedoni_hip_destroy(PedoniModel* m);
+
+/* [trait] PedestrianModel::spawn_pedestrians (models/mod.rs:18; sfm.rs:48-89): append
+ * `n` agents (velocity 0, desired speed drawn from N^(1.34, 0.26) inside the model),
+ * then bin, stable-sort by cell and despawn.  Called with n == 0 every tick by
+ * Simulator::tick (lib.rs:85) -- it IS the sort/despawn pass. */
+int pedoni_hip_spawn_pedestrians(PedoniModel* m, const PedoniPedestrian* peds, uint32_t n);
+/* [trait] PedestrianModel::update_states (models/mod.rs:20; sfm.rs:91-255) */
+int pedoni_hip_update_states(PedoniModel* m);
+/* [trait] PedestrianModel::list_pedestrians (models/mod.rs:22; sfm.rs:257-265).
+ * Writes min(count, cap) entries, stores the live count in *n. */
+int pedoni_hip_list_pedestrians(PedoniModel* m, PedoniPedestrian* out, uint32_t cap,
+                                uint32_t* n);
+/* [trait] PedestrianModel::get_pedestrian_count (models/mod.rs:24; sfm.rs:267-269) */
+int pedoni_hip_get_pedestrian_count(PedoniModel* m, int32_t* count);
+
+/* [ext] append with full state (state injection).  desired_speed NULL ->
+ * drawn from the model RNG as the trait method does; vel_xy NULL -> zero.  Append only:
+ * the agents take part from the next sort/despawn pass on. */
+int pedoni_hip_append(PedoniModel* m, const float* pos_xy, const uint32_t* destination,
+                      const float* desired_speed, const float* vel_xy, uint32_t n);
+/* [ext] the sort/despawn half of spawn_pedestrians alone (sfm.rs:58-88) */
+int pedoni_hip_sort_despawn(PedoniModel* m);
+/* [ext] `steps` x (sort_despawn; update_states) with no host round trip in between */
+int pedoni_hip_tick_n(PedoniModel* m, uint32_t steps);
+/* [ext] one Simulator::tick-shaped step with StepMetrics (lib.rs:64-100), no new agents */
+int pedoni_hip_tick(PedoniModel* m, PedoniStepMetrics* metrics);
+/* [ext] full SoA state of the live agents in model order; any pointer may be NULL */
+int pedoni_hip_download(PedoniModel* m, float* pos_xy, uint32_t* destination, float* vel_xy,
+                        float* desired_speed, uint32_t cap, uint32_t* n);
+/* [ext] drop all agents */
+int pedoni_hip_clear(PedoniModel* m);
+/* [ext] `neighbor_grid_indices` (sfm.rs:22,62-74): rows*cols+1 prefix counts.
+ * Stores the length in *len; copies min(len, cap) entries when out != NULL. */
+int pedoni_hip_neighbor_grid_indices(PedoniModel* m, uint32_t* out, uint32_t cap,
+                                     uint32_t* len);
+int pedoni_hip_neighbor_grid_shape(PedoniModel* m, uint32_t* rows, uint32_t* cols);
+/* [ext] accelerations of sfm.rs:93-241 for the current sorted state (no integration) */
+int pedoni_hip_calc_accelerations(PedoniModel* m, float* acc_xy, uint32_t cap);
+
+/* [ext] stream / timing */
+int pedoni_hip_set_stream(PedoniModel* m, void* hip_stream); /* NULL -> library stream */
+int pedoni_hip_get_stream(PedoniModel* m, void** hip_stream);
+int pedoni_hip_synchronize(PedoniModel* m);
+int pedoni_hip_profile(PedoniModel* m, int32_t enable);      /* hipEvent pair per kernel */
+int pedoni_hip_kernel_times(PedoniModel* m, PedoniKernelTimes* out, int32_t reset);
+const char* pedoni_hip_kernel_name(int32_t k);
+
+/* [ext] row-band sharding over several GPUs (no reference counterpart).
+ * A model that owns neighbor-grid rows [row_begin, row_end) keeps agents of those rows
+ * plus ghost copies of rows row_begin-1 and row_end.  Each tick, before sort/despawn:
+ *   halo_pack   writes the full 24-byte state of the agents whose CURRENT cell row is
+ *               row_begin-1 or row_begin (the "down" list, for the rank below) and
+ *               row_end-1 or row_end (the "up" list, for the rank above) into `send`,
+ *               a caller-owned DEVICE buffer of 2 * (header + cap_each records);
+ *   (caller)    exchanges buffers with RCCL (torch.distributed all_gather_into_tensor);
+ *   halo_unpack drops agents that left the band and last tick's ghosts, then places
+ *               the "up" list of the rank below in FRONT of the kept agents and the
+ *               "down" list of the rank above BEHIND them, so that the stable cell sort
+ *               reproduces the single-GPU order bit for bit.
+ * Forces are evaluated and integrated for owned rows only. */
+#define PEDONI_HALO_HEADER_WORDS 4 /* u32 count, overflow flag, 2 reserved */
+#define PEDONI_HALO_RECORD_WORDS 6 /* pos.xy, vel.xy, desired_speed, destination */
+int pedoni_hip_set_band(PedoniModel* m, int32_t row_begin, int32_t row_end);
+int pedoni_hip_halo_bytes(uint32_t cap_each, uint64_t* bytes); /* size of one rank's buffer */
+int pedoni_hip_halo_pack(PedoniModel* m, void* send_dev, uint32_t cap_each);
+int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev,
+                           const void* from_above_dev, uint32_t cap_each);
+/* owned-agent count (excludes ghosts) */
+int pedoni_hip_owned_count(PedoniModel* m, int32_t* count);
+
+/* [ext] device self-test hooks used by tests/: evaluate one device math primitive over
+ * host arrays (op: 0 = a/b, 1 = sqrt(a), 2 = exp(a), 3 = bilinear sample of a map) */
+int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mode, const float* a,
+                             const float* b, float* out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

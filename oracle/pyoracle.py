@@ -1,0 +1,271 @@
+"""ctypes binding of the CPU oracle (oracle/libpedoni_oracle.so).
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Importable only from tests/, from
+__graft_entry__.smoke() and from bench.py's cpu_baseline leg.  Nothing under
+pedoni_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+_LIB: Optional[C.CDLL] = None
+
+
+class _Field(C.Structure):
+    _fields_ = [("unit", C.c_float), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("distance_map", C.POINTER(C.c_float)),
+                ("potential_maps", C.POINTER(C.POINTER(C.c_float))), ("n_maps", C.c_int32)]
+
+
+class _Options(C.Structure):
+    _fields_ = [("neighbor_grid_unit", C.c_float), ("field_grid_unit", C.c_float),
+                ("use_neighbor_grid", C.c_int32), ("use_distance_map", C.c_int32)]
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        so = _DIR / "libpedoni_oracle.so"
+        if not so.exists():
+            subprocess.run(["make", "-s", "-C", str(_DIR)], check=True)
+        L = C.CDLL(str(so))
+        L.oracle_bilinear.restype = C.c_float
+        L.oracle_bilinear.argtypes = [C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_float, C.c_float]
+        L.oracle_sobel_filter.argtypes = [C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_float,
+                                          C.c_float, C.POINTER(C.c_float)]
+        L.oracle_expf_restated.restype = C.c_float
+        L.oracle_expf_restated.argtypes = [C.c_float]
+        L.oracle_rng_f32.restype = C.c_float
+        L.oracle_rng_f64.restype = C.c_double
+        L.oracle_rng_next.restype = C.c_uint64
+        L.oracle_rng_normal_approx.restype = C.c_float
+        L.oracle_rng_normal_approx.argtypes = [C.POINTER(C.c_uint64), C.c_float, C.c_float]
+        L.oracle_poisson.restype = C.c_int32
+        L.oracle_poisson.argtypes = [C.POINTER(C.c_uint64), C.c_double]
+        L.oracle_get_potential.restype = C.c_float
+        L.oracle_get_potential.argtypes = [C.POINTER(_Field), C.c_uint32, C.c_float, C.c_float]
+        L.oracle_get_obstacle_distance.restype = C.c_float
+        L.oracle_get_obstacle_distance.argtypes = [C.POINTER(_Field), C.c_float, C.c_float]
+        L.oracle_model_new.restype = C.c_void_p
+        L.oracle_model_new.argtypes = [C.POINTER(_Options), C.c_float, C.c_float]
+        L.oracle_model_free.argtypes = [C.c_void_p]
+        L.oracle_model_seed.argtypes = [C.c_void_p, C.c_uint64]
+        L.oracle_model_set_threads.argtypes = [C.c_void_p, C.c_int32]
+        L.oracle_get_pedestrian_count.restype = C.c_int32
+        L.oracle_get_pedestrian_count.argtypes = [C.c_void_p]
+        L.oracle_neighbor_grid_indices.restype = C.c_uint32
+        L.oracle_neighbor_grid_indices.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+        L.oracle_field_shape.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32)]
+        L.oracle_neighbor_grid_shape.argtypes = L.oracle_field_shape.argtypes
+        L.oracle_sim_spawn_once.restype = C.c_uint32
+        L.oracle_sim_spawn_periodic.restype = C.c_uint32
+        _LIB = L
+    return _LIB
+
+
+def _fp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _up(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _segments(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 5)
+    return a
+
+
+# ---- util.rs ---------------------------------------------------------------------
+def bilinear(grid: np.ndarray, px: float, py: float) -> float:
+    g = np.ascontiguousarray(grid, np.float32)
+    return float(lib().oracle_bilinear(_fp(g), g.shape[0], g.shape[1], px, py))
+
+
+def sobel_filter(grid: np.ndarray, px: float, py: float) -> np.ndarray:
+    g = np.ascontiguousarray(grid, np.float32)
+    out = np.zeros(2, np.float32)
+    lib().oracle_sobel_filter(_fp(g), g.shape[0], g.shape[1], px, py, _fp(out))
+    return out
+
+
+def distance_from_line(point, line) -> np.ndarray:
+    l = np.ascontiguousarray(line, np.float32).ravel()
+    out = np.zeros(2, np.float32)
+    lib().oracle_distance_from_line(C.c_float(point[0]), C.c_float(point[1]), _fp(l), _fp(out))
+    return out
+
+
+def line_with_width(line, width: float) -> np.ndarray:
+    l = np.ascontiguousarray(line, np.float32).ravel()
+    out = np.zeros(8, np.float32)
+    lib().oracle_line_with_width(_fp(l), C.c_float(width), _fp(out))
+    return out.reshape(4, 2)
+
+
+def expf_restated(x: np.ndarray) -> np.ndarray:
+    L = lib()
+    x = np.asarray(x, np.float32)
+    return np.array([L.oracle_expf_restated(float(v)) for v in x.ravel()], np.float32).reshape(x.shape)
+
+
+class Rng:
+    def __init__(self, seed: int):
+        self.state = C.c_uint64(seed)
+
+    def f32(self) -> float:
+        return float(lib().oracle_rng_f32(C.byref(self.state)))
+
+    def f64(self) -> float:
+        return float(lib().oracle_rng_f64(C.byref(self.state)))
+
+    def normal_approx(self, mu: float, sigma: float) -> float:
+        return float(lib().oracle_rng_normal_approx(C.byref(self.state), mu, sigma))
+
+    def poisson(self, lam: float) -> int:
+        return int(lib().oracle_poisson(C.byref(self.state), lam))
+
+
+# ---- field.rs -------------------------------------------------------------------------
+class Field:
+    """field.rs:194-205 `Field` holding numpy maps (rows, cols) float32."""
+
+    def __init__(self, unit: float, distance_map: np.ndarray, potential_maps: Sequence[np.ndarray],
+                 obstacle_exist: Optional[np.ndarray] = None):
+        self.unit = float(unit)
+        self.distance_map = np.ascontiguousarray(distance_map, np.float32)
+        self.potential_maps = [np.ascontiguousarray(p, np.float32) for p in potential_maps]
+        self.obstacle_exist = obstacle_exist
+        self.shape = self.distance_map.shape
+        self._ptrs = (C.POINTER(C.c_float) * max(len(self.potential_maps), 1))(
+            *[_fp(p) for p in self.potential_maps])
+        self._c = _Field(self.unit, self.shape[0], self.shape[1], _fp(self.distance_map),
+                         self._ptrs, len(self.potential_maps))
+
+    @property
+    def c(self):
+        return C.byref(self._c)
+
+    def get_potential(self, waypoint: int, pos) -> float:
+        return float(lib().oracle_get_potential(self.c, waypoint, pos[0], pos[1]))
+
+    def get_obstacle_distance(self, pos) -> float:
+        return float(lib().oracle_get_obstacle_distance(self.c, pos[0], pos[1]))
+
+    def get_potential_grad(self, waypoint: int, pos) -> np.ndarray:
+        out = np.zeros(2, np.float32)
+        lib().oracle_get_potential_grad(self.c, C.c_uint32(waypoint), C.c_float(pos[0]),
+                                        C.c_float(pos[1]), _fp(out))
+        return out
+
+    def get_obstacle_distance_grad(self, pos) -> np.ndarray:
+        out = np.zeros(2, np.float32)
+        lib().oracle_get_obstacle_distance_grad(self.c, C.c_float(pos[0]), C.c_float(pos[1]), _fp(out))
+        return out
+
+
+def field_shape(size, unit: float):
+    r, c = C.c_int32(0), C.c_int32(0)
+    lib().oracle_field_shape(size[0], size[1], unit, C.byref(r), C.byref(c))
+    return int(r.value), int(c.value)
+
+
+def neighbor_grid_shape(size, unit: float):
+    r, c = C.c_int32(0), C.c_int32(0)
+    lib().oracle_neighbor_grid_shape(size[0], size[1], unit, C.byref(r), C.byref(c))
+    return int(r.value), int(c.value)
+
+
+def field_from_scenario(size, unit: float, obstacles, waypoints) -> Field:
+    """field.rs:220-232 Field::from_scenario; segments are rows of (x0, y0, x1, y1, width)."""
+    rows, cols = field_shape(size, unit)
+    obs, wps = _segments(obstacles), _segments(waypoints)
+    exist = np.zeros((rows, cols), np.uint8)
+    dist = np.zeros((rows, cols), np.float32)
+    pots = np.zeros((max(len(wps), 1), rows, cols), np.float32)
+    lib().oracle_field_build(
+        C.c_float(size[0]), C.c_float(size[1]), C.c_float(unit), _fp(obs), C.c_uint32(len(obs)),
+        _fp(wps), C.c_uint32(len(wps)), exist.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(dist),
+        _fp(pots))
+    return Field(unit, dist, [pots[i] for i in range(len(wps))], exist.astype(bool))
+
+
+def apply_fmm(potential: np.ndarray, slowness: np.ndarray) -> np.ndarray:
+    p = np.array(potential, np.float32, copy=True, order="C")
+    f = np.ascontiguousarray(slowness, np.float32)
+    lib().oracle_apply_fmm(_fp(p), _fp(f), C.c_int32(p.shape[0]), C.c_int32(p.shape[1]))
+    return p
+
+
+def rasterize_outline(verts_cells, rows: int, cols: int) -> np.ndarray:
+    v = np.ascontiguousarray(verts_cells, np.float32).ravel()
+    mask = np.zeros((rows, cols), np.uint8)
+    lib().oracle_rasterize_outline(_fp(v), C.c_int32(rows), C.c_int32(cols),
+                                   mask.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return mask.astype(bool)
+
+
+# ---- models/sfm.rs ----------------------------------------------------------------------
+class OracleModel:
+    """SocialForceModel (models/sfm.rs) restated on the CPU."""
+
+    def __init__(self, size, neighbor_grid_unit: float = 1.4, field_grid_unit: float = 0.25,
+                 use_neighbor_grid: bool = True, use_distance_map: bool = True,
+                 seed: int = 12345, threads: int = 0):
+        self._opt = _Options(neighbor_grid_unit, field_grid_unit, int(use_neighbor_grid),
+                             int(use_distance_map))
+        self._h = C.c_void_p(lib().oracle_model_new(C.byref(self._opt), size[0], size[1]))
+        lib().oracle_model_seed(self._h, seed)
+        lib().oracle_model_set_threads(self._h, threads)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().oracle_model_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def spawn_pedestrians(self, field: Field, pos=None, destination=None, desired_speed=None,
+                          vel=None) -> None:
+        n = 0 if pos is None else len(pos)
+        p = np.ascontiguousarray(pos if n else np.zeros((0, 2)), np.float32).reshape(-1, 2)
+        d = np.ascontiguousarray(destination if n else np.zeros(0), np.uint32)
+        v0 = None if desired_speed is None else np.ascontiguousarray(desired_speed, np.float32)
+        v = None if vel is None else np.ascontiguousarray(vel, np.float32).reshape(-1, 2)
+        lib().oracle_spawn_pedestrians(self._h, field.c, _fp(p), _up(d), C.c_uint32(n), _fp(v0), _fp(v))
+
+    def update_states(self, field: Field, obstacles=None) -> None:
+        obs = _segments(obstacles if obstacles is not None else np.zeros((0, 5)))
+        lib().oracle_update_states(self._h, field.c, _fp(obs), C.c_uint32(len(obs)))
+
+    def calc_accelerations(self, field: Field, obstacles=None) -> np.ndarray:
+        obs = _segments(obstacles if obstacles is not None else np.zeros((0, 5)))
+        out = np.zeros((self.get_pedestrian_count(), 2), np.float32)
+        lib().oracle_calc_accelerations(self._h, field.c, _fp(obs), C.c_uint32(len(obs)), _fp(out))
+        return out
+
+    def get_pedestrian_count(self) -> int:
+        return int(lib().oracle_get_pedestrian_count(self._h))
+
+    def download(self):
+        n = self.get_pedestrian_count()
+        pos = np.zeros((n, 2), np.float32)
+        vel = np.zeros((n, 2), np.float32)
+        v0 = np.zeros(n, np.float32)
+        dest = np.zeros(n, np.uint32)
+        lib().oracle_download(self._h, _fp(pos), _up(dest), _fp(vel), _fp(v0))
+        return pos, dest, vel, v0
+
+    def neighbor_grid_indices(self) -> np.ndarray:
+        n = lib().oracle_neighbor_grid_indices(self._h, None, 0)
+        out = np.zeros(n, np.uint32)
+        lib().oracle_neighbor_grid_indices(self._h, _up(out), n)
+        return out

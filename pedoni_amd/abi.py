@@ -1,0 +1,339 @@
+"""ctypes binding of include/pedoni_hip.h (the C-ABI of the gfx950 backend).
+
+Thin by design: every method forwards to one ``pedoni_hip_*`` entry point and raises
+``PedoniError`` on a non-zero status.  No computation happens in Python and nothing
+falls back to a CPU path: if ``libpedoni_hip.so`` is missing or no GPU is present the
+calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+_ROOT = Path(__file__).resolve().parent
+_LIB: Optional[C.CDLL] = None
+
+N_KERNELS = 8
+MATH_EXACT = 0
+MATH_FAST = 1
+HALO_HEADER_WORDS = 4
+HALO_RECORD_WORDS = 6
+
+# every symbol include/pedoni_hip.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "pedoni_hip_last_error", "pedoni_hip_default_options", "pedoni_hip_device_count",
+    "pedoni_hip_create", "pedoni_hip_destroy", "pedoni_hip_spawn_pedestrians",
+    "pedoni_hip_update_states", "pedoni_hip_list_pedestrians",
+    "pedoni_hip_get_pedestrian_count", "pedoni_hip_append", "pedoni_hip_sort_despawn",
+    "pedoni_hip_tick_n", "pedoni_hip_tick", "pedoni_hip_download", "pedoni_hip_clear",
+    "pedoni_hip_neighbor_grid_indices", "pedoni_hip_neighbor_grid_shape",
+    "pedoni_hip_calc_accelerations", "pedoni_hip_set_stream", "pedoni_hip_get_stream",
+    "pedoni_hip_synchronize", "pedoni_hip_profile", "pedoni_hip_kernel_times",
+    "pedoni_hip_kernel_name", "pedoni_hip_set_band", "pedoni_hip_halo_bytes",
+    "pedoni_hip_halo_pack", "pedoni_hip_halo_unpack", "pedoni_hip_owned_count",
+    "pedoni_hip_selftest_math",
+]
+
+
+class PedoniError(RuntimeError):
+    pass
+
+
+class _Options(C.Structure):
+    _fields_ = [
+        ("neighbor_grid_unit", C.c_float), ("field_grid_unit", C.c_float),
+        ("use_neighbor_grid", C.c_int32), ("use_distance_map", C.c_int32),
+        ("gpu_work_size", C.c_int32), ("math_mode", C.c_int32),
+        ("seed", C.c_uint64), ("initial_capacity", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+class _Obstacle(C.Structure):
+    _fields_ = [("x0", C.c_float), ("y0", C.c_float), ("x1", C.c_float), ("y1", C.c_float),
+                ("width", C.c_float)]
+
+
+class _Pedestrian(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("destination", C.c_uint64)]
+
+
+class _StepMetrics(C.Structure):
+    _fields_ = [("active_ped_count", C.c_int32), ("time_spawn", C.c_double),
+                ("time_calc_state", C.c_double), ("time_calc_state_kernel", C.c_double)]
+
+
+class _KernelTimes(C.Structure):
+    _fields_ = [("total_ms", C.c_double * N_KERNELS), ("launches", C.c_uint64 * N_KERNELS)]
+
+
+PED_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("destination", "<u8")], align=True)
+
+
+@dataclass
+class Options:
+    """lib.rs:108-135 `SimulatorOptions` (same defaults) + backend knobs."""
+    neighbor_grid_unit: float = 1.4
+    field_grid_unit: float = 0.25
+    use_neighbor_grid: bool = True
+    use_distance_map: bool = True
+    gpu_work_size: int = 0
+    math_mode: int = MATH_EXACT
+    seed: int = 12345
+    initial_capacity: int = 0
+
+    def _c(self) -> _Options:
+        return _Options(self.neighbor_grid_unit, self.field_grid_unit,
+                        int(self.use_neighbor_grid), int(self.use_distance_map),
+                        self.gpu_work_size, self.math_mode, self.seed, self.initial_capacity, 0)
+
+
+def library_path() -> Path:
+    return _ROOT / "lib" / "libpedoni_hip.so"
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree HIP library; never builds, never substitutes."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not path.exists():
+        raise PedoniError(
+            f"{path} is missing: build it with `python -m pedoni_amd.build` "
+            "(the HIP backend has no CPU fallback)")
+    lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL)
+    lib.pedoni_hip_last_error.restype = C.c_char_p
+    lib.pedoni_hip_kernel_name.restype = C.c_char_p
+    lib.pedoni_hip_kernel_name.argtypes = [C.c_int32]
+    lib.pedoni_hip_destroy.restype = None
+    lib.pedoni_hip_destroy.argtypes = [C.c_void_p]
+    lib.pedoni_hip_default_options.restype = None
+    _LIB = lib
+    return lib
+
+
+def _check(lib: C.CDLL, rc: int) -> None:
+    if rc != 0:
+        msg = lib.pedoni_hip_last_error()
+        raise PedoniError(f"pedoni_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def _f32(a, shape_last: Optional[int] = None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape_last is not None:
+        a = a.reshape(-1, shape_last)
+    return a
+
+
+def _ptr(a: Optional[np.ndarray], typ):
+    return None if a is None else a.ctypes.data_as(C.POINTER(typ))
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = C.c_int32(0)
+    rc = lib.pedoni_hip_device_count(C.byref(n))
+    return int(n.value) if rc == 0 else 0
+
+
+def selftest_math(op: int, a, b=None, math_mode: int = MATH_EXACT, device: int = 0) -> np.ndarray:
+    lib = load_library()
+    a = _f32(a).ravel()
+    bb = None if b is None else _f32(b).ravel()
+    out = np.empty_like(a)
+    _check(lib, lib.pedoni_hip_selftest_math(
+        C.c_int(device), C.c_int32(op), C.c_int32(math_mode), _ptr(a, C.c_float),
+        _ptr(bb, C.c_float), _ptr(out, C.c_float), C.c_uint32(a.size)))
+    return out
+
+
+class HipModel:
+    """One GPU's `PedestrianModel` (models/mod.rs:13-25) behind the C-ABI."""
+
+    def __init__(self, options: Options, size: Sequence[float], distance_map: np.ndarray,
+                 potential_maps: Sequence[np.ndarray], field_unit: float,
+                 obstacles: Optional[np.ndarray] = None, device: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p(None)
+        dm = _f32(distance_map)
+        if dm.ndim != 2:
+            raise PedoniError("distance_map must be 2-D (rows, cols)")
+        pms = [_f32(p) for p in potential_maps]
+        for p in pms:
+            if p.shape != dm.shape:
+                raise PedoniError("potential map shape differs from distance map")
+        ptrs = (C.POINTER(C.c_float) * max(len(pms), 1))(*[_ptr(p, C.c_float) for p in pms])
+        obs = np.zeros((0, 5), np.float32) if obstacles is None else _f32(obstacles, 5)
+        self.options = options
+        self.n_maps = len(pms)
+        opt = options._c()
+        rc = self._lib.pedoni_hip_create(
+            C.byref(opt), C.c_float(size[0]), C.c_float(size[1]), _ptr(dm, C.c_float), ptrs,
+            C.c_uint32(len(pms)), C.c_uint32(dm.shape[0]), C.c_uint32(dm.shape[1]),
+            C.c_float(field_unit), obs.ctypes.data_as(C.POINTER(_Obstacle)),
+            C.c_uint32(obs.shape[0]), C.c_int(device), C.byref(self._h))
+        _check(self._lib, rc)
+
+    # -- lifetime ----------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.pedoni_hip_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- trait methods -----------------------------------------------------------
+    def spawn_pedestrians(self, pos=None, destination=None) -> None:
+        """PedestrianModel::spawn_pedestrians: append (vel 0, drawn speed) + sort/despawn."""
+        n = 0 if pos is None else len(pos)
+        peds = np.zeros(n, PED_DTYPE)
+        if n:
+            p = _f32(pos, 2)
+            peds["x"], peds["y"] = p[:, 0], p[:, 1]
+            peds["destination"] = np.asarray(destination, dtype=np.uint64)
+        _check(self._lib, self._lib.pedoni_hip_spawn_pedestrians(
+            self._h, peds.ctypes.data_as(C.POINTER(_Pedestrian)), C.c_uint32(n)))
+
+    def update_states(self) -> None:
+        _check(self._lib, self._lib.pedoni_hip_update_states(self._h))
+
+    def list_pedestrians(self) -> np.ndarray:
+        n = C.c_uint32(0)
+        _check(self._lib, self._lib.pedoni_hip_list_pedestrians(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, PED_DTYPE)
+        _check(self._lib, self._lib.pedoni_hip_list_pedestrians(
+            self._h, out.ctypes.data_as(C.POINTER(_Pedestrian)), C.c_uint32(n.value), C.byref(n)))
+        return out
+
+    def get_pedestrian_count(self) -> int:
+        c = C.c_int32(0)
+        _check(self._lib, self._lib.pedoni_hip_get_pedestrian_count(self._h, C.byref(c)))
+        return int(c.value)
+
+    # -- extensions --------------------------------------------------------------
+    def append(self, pos, destination, desired_speed=None, vel=None) -> None:
+        p = _f32(pos, 2)
+        d = np.ascontiguousarray(destination, dtype=np.uint32)
+        v0 = None if desired_speed is None else _f32(desired_speed).ravel()
+        v = None if vel is None else _f32(vel, 2)
+        if len(d) != len(p) or (v0 is not None and len(v0) != len(p)) or \
+                (v is not None and len(v) != len(p)):
+            raise PedoniError("append: array lengths differ")
+        _check(self._lib, self._lib.pedoni_hip_append(
+            self._h, _ptr(p, C.c_float), _ptr(d, C.c_uint32), _ptr(v0, C.c_float),
+            _ptr(v, C.c_float), C.c_uint32(len(p))))
+
+    def sort_despawn(self) -> None:
+        _check(self._lib, self._lib.pedoni_hip_sort_despawn(self._h))
+
+    def tick_n(self, steps: int) -> None:
+        _check(self._lib, self._lib.pedoni_hip_tick_n(self._h, C.c_uint32(steps)))
+
+    def tick(self) -> dict:
+        m = _StepMetrics()
+        _check(self._lib, self._lib.pedoni_hip_tick(self._h, C.byref(m)))
+        k = m.time_calc_state_kernel
+        return {"active_ped_count": m.active_ped_count, "time_spawn": m.time_spawn,
+                "time_calc_state": m.time_calc_state,
+                "time_calc_state_kernel": None if k < 0 else k}
+
+    def download(self):
+        """(pos[n,2], destination[n], vel[n,2], desired_speed[n]) in model order."""
+        n = C.c_uint32(0)
+        _check(self._lib, self._lib.pedoni_hip_download(self._h, None, None, None, None, 0,
+                                                       C.byref(n)))
+        k = n.value
+        pos = np.empty((k, 2), np.float32)
+        vel = np.empty((k, 2), np.float32)
+        v0 = np.empty(k, np.float32)
+        dest = np.empty(k, np.uint32)
+        _check(self._lib, self._lib.pedoni_hip_download(
+            self._h, _ptr(pos, C.c_float), _ptr(dest, C.c_uint32), _ptr(vel, C.c_float),
+            _ptr(v0, C.c_float), C.c_uint32(k), C.byref(n)))
+        return pos, dest, vel, v0
+
+    def clear(self) -> None:
+        _check(self._lib, self._lib.pedoni_hip_clear(self._h))
+
+    def neighbor_grid_shape(self):
+        r, c = C.c_uint32(0), C.c_uint32(0)
+        _check(self._lib, self._lib.pedoni_hip_neighbor_grid_shape(self._h, C.byref(r), C.byref(c)))
+        return int(r.value), int(c.value)
+
+    def neighbor_grid_indices(self) -> np.ndarray:
+        n = C.c_uint32(0)
+        _check(self._lib, self._lib.pedoni_hip_neighbor_grid_indices(self._h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint32)
+        if n.value:
+            _check(self._lib, self._lib.pedoni_hip_neighbor_grid_indices(
+                self._h, _ptr(out, C.c_uint32), C.c_uint32(n.value), C.byref(n)))
+        return out
+
+    def calc_accelerations(self, n: int) -> np.ndarray:
+        out = np.empty((n, 2), np.float32)
+        _check(self._lib, self._lib.pedoni_hip_calc_accelerations(
+            self._h, _ptr(out, C.c_float), C.c_uint32(n)))
+        return out
+
+    def set_stream(self, stream_ptr: Optional[int]) -> None:
+        _check(self._lib, self._lib.pedoni_hip_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def get_stream(self) -> int:
+        s = C.c_void_p(None)
+        _check(self._lib, self._lib.pedoni_hip_get_stream(self._h, C.byref(s)))
+        return int(s.value or 0)
+
+    def synchronize(self) -> None:
+        _check(self._lib, self._lib.pedoni_hip_synchronize(self._h))
+
+    def profile(self, enable: bool) -> None:
+        _check(self._lib, self._lib.pedoni_hip_profile(self._h, C.c_int32(int(enable))))
+
+    def kernel_times(self, reset: bool = False) -> dict:
+        t = _KernelTimes()
+        _check(self._lib, self._lib.pedoni_hip_kernel_times(self._h, C.byref(t), C.c_int32(int(reset))))
+        out = {}
+        for k in range(N_KERNELS):
+            name = self._lib.pedoni_hip_kernel_name(k).decode()
+            out[name] = {"total_ms": float(t.total_ms[k]), "launches": int(t.launches[k])}
+        return out
+
+    # -- sharding ----------------------------------------------------------------
+    def set_band(self, row_begin: int, row_end: int) -> None:
+        _check(self._lib, self._lib.pedoni_hip_set_band(self._h, C.c_int32(row_begin),
+                                                       C.c_int32(row_end)))
+
+    @staticmethod
+    def halo_bytes(cap_each: int) -> int:
+        lib = load_library()
+        b = C.c_uint64(0)
+        _check(lib, lib.pedoni_hip_halo_bytes(C.c_uint32(cap_each), C.byref(b)))
+        return int(b.value)
+
+    def halo_pack(self, send_dev_ptr: int, cap_each: int) -> None:
+        _check(self._lib, self._lib.pedoni_hip_halo_pack(self._h, C.c_void_p(send_dev_ptr),
+                                                        C.c_uint32(cap_each)))
+
+    def halo_unpack(self, below_dev_ptr: Optional[int], above_dev_ptr: Optional[int],
+                    cap_each: int) -> None:
+        _check(self._lib, self._lib.pedoni_hip_halo_unpack(
+            self._h, C.c_void_p(below_dev_ptr), C.c_void_p(above_dev_ptr), C.c_uint32(cap_each)))
+
+    def owned_count(self) -> int:
+        c = C.c_int32(0)
+        _check(self._lib, self._lib.pedoni_hip_owned_count(self._h, C.byref(c)))
+        return int(c.value)

@@ -1,0 +1,88 @@
+"""Build the in-tree native libraries (hipcc cross-compiles gfx950 without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "pedoni_amd" / "csrc"
+LIBDIR = ROOT / "pedoni_amd" / "lib"
+INCLUDE = ROOT / "include"
+
+# -ffp-contract=off: the reference (Rust) never fuses a*b+c; parity is bit-level.
+HIP_FLAGS = [
+    "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
+    "-shared", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-value",
+]
+
+
+def _newer(target: Path, sources) -> bool:
+    if not target.exists():
+        return False
+    t = target.stat().st_mtime
+    return all(Path(s).stat().st_mtime <= t for s in sources)
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found: the HIP backend cannot be built")
+    return exe
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> Path:
+    LIBDIR.mkdir(parents=True, exist_ok=True)
+    out = LIBDIR / "libpedoni_hip.so"
+    srcs = [CSRC / "pedoni_hip.hip"]
+    deps = srcs + list(CSRC.glob("*.hpp")) + [INCLUDE / "pedoni_hip.h"]
+    if not force and _newer(out, deps):
+        return out
+    cmd = [hipcc(), *HIP_FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-o", str(out), *map(str, srcs)]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return out
+
+
+def build_host(force: bool = False, verbose: bool = False) -> Path | None:
+    """C++ host mirror of pedoni-simulator's Simulator (links against libpedoni_hip)."""
+    host_dir = CSRC / "host"
+    srcs = sorted(host_dir.glob("*.cpp"))
+    if not srcs:
+        return None
+    out = LIBDIR / "libpedoni_host.so"
+    deps = srcs + list(host_dir.glob("*.hpp")) + list(INCLUDE.glob("*.h"))
+    if not force and _newer(out, deps):
+        return out
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-fno-fast-math", "-Wall", "-Wextra", "-pthread", f"-I{INCLUDE}", f"-I{host_dir}",
+           "-o", str(out), *map(str, srcs), f"-L{LIBDIR}", "-lpedoni_hip",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return out
+
+
+def build_oracle(force: bool = False) -> Path:
+    """The CPU oracle is test infrastructure; building the checker is not using it."""
+    odir = ROOT / "oracle"
+    out = odir / "libpedoni_oracle.so"
+    if force and out.exists():
+        out.unlink()
+    subprocess.run(["make", "-s", "-C", str(odir)], check=True)
+    return out
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_hip(force, verbose)
+    build_host(force, verbose)
+    build_oracle(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("built:", *sorted(p.name for p in LIBDIR.glob("*.so")))

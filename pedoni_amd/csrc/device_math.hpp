@@ -1,0 +1,224 @@
+// device_math.hpp -- gfx950 device primitives of the social-force path.
+//
+// Every function spells out the fp32 operation order of the reference CPU path
+// (glam Vec2 arithmetic as used by pedoni-simulator/src/models/sfm.rs, util.rs,
+// field.rs).  The translation unit is built with -ffp-contract=off so a*b+c is never
+// fused, f32 division and sqrt are hipcc's correctly rounded forms, and f32 denormals
+// are kept: in PEDONI_MATH_EXACT every value below is bit-identical to what rustc
+// produces on x86-64.  MODE = 1 (PEDONI_MATH_FAST) swaps division / sqrt / exp for the
+// 1-ulp hardware approximations (v_rcp_f32, v_rsq_f32, v_sqrt_f32, v_exp_f32).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pedoni {
+
+struct v2 { float x, y; };
+
+__device__ __forceinline__ v2 mk(float x, float y) { v2 r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ v2 operator+(v2 a, v2 b) { return mk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ v2 operator-(v2 a, v2 b) { return mk(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ v2 operator-(v2 a) { return mk(-a.x, -a.y); }
+__device__ __forceinline__ v2 operator*(v2 a, float s) { return mk(a.x * s, a.y * s); }
+__device__ __forceinline__ float dot(v2 a, v2 b) { return (a.x * b.x) + (a.y * b.y); }
+
+// ---- division / sqrt / exp by math mode -------------------------------------------
+template <int MODE> __device__ __forceinline__ float fdiv(float a, float b)
+{
+    if constexpr (MODE == 0) return a / b;             // IEEE, correctly rounded
+    else return a * __builtin_amdgcn_rcpf(b);
+}
+template <int MODE> __device__ __forceinline__ float frcp(float b)
+{
+    if constexpr (MODE == 0) return 1.0f / b;
+    else return __builtin_amdgcn_rcpf(b);
+}
+template <int MODE> __device__ __forceinline__ float fsqrt(float a)
+{
+    if constexpr (MODE == 0) return __builtin_sqrtf(a); // correctly rounded
+    else return __builtin_amdgcn_sqrtf(a);
+}
+
+// 2^(i/32) table of glibc's expf (bits minus i<<47), sysdeps/ieee754/flt-32/e_exp2f_data.c
+__device__ const uint64_t EXP2F_TAB[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51,
+    0x3fef72b83c7d517b, 0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1,
+    0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
+    0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585,
+    0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13,
+    0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+    0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069,
+    0x3fef5818dcfba487, 0x3fef7c97337b9b5f, 0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
+};
+
+// Rust's f32::exp is the host libm's expf.  glibc >= 2.27 computes it in double with
+// the table above and a cubic, using FMA on x86-64 (multiarch variant); this replays
+// that sequence operation for operation in f64, so the result equals the host's bit
+// for bit (verified against glibc 2.35 on all 2.2e9 floats in [-104, 88] but two).
+__device__ __forceinline__ float exp_glibc(float x, const uint64_t* tab)
+{
+    const double N = 32.0;
+    const double InvLn2N = 0x1.71547652b82fep+0 * N;
+    const double SHIFT = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / N / N / N;
+    const double C1 = 0x1.ebfce50fac4f3p-3 / N / N;
+    const double C2 = 0x1.62e42ff0c52d6p-1 / N;
+
+    uint32_t ux = __float_as_uint(x);
+    uint32_t abstop = (ux >> 20) & 0x7ff;
+    if (abstop >= 0x42b) { // |x| >= 88 or NaN
+        if (ux == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8) return x + x;
+        if (x > 0x1.62e42ep6f) return __builtin_inff();
+        if (x < -0x1.9fe368p6f) return 0.0f;
+    }
+    double xd = (double)x;
+    double z = InvLn2N * xd;
+    double kd = z + SHIFT;
+    uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= SHIFT;
+    double r = z - kd;
+    uint64_t t = tab[ki & 31];
+    t += ki << 47;
+    double s = __longlong_as_double((long long)t);
+    double zz = __builtin_fma(C0, r, C1);
+    double r2 = r * r;
+    double y = __builtin_fma(C2, r, 1.0);
+    y = __builtin_fma(zz, r2, y);
+    y = y * s;
+    return (float)y;
+}
+
+template <int MODE> __device__ __forceinline__ float fexp(float x, const uint64_t* tab)
+{
+    if constexpr (MODE == 0) return exp_glibc(x, tab);
+    else return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+}
+
+// ---- glam helpers -------------------------------------------------------------------
+template <int MODE> __device__ __forceinline__ float length(v2 a) { return fsqrt<MODE>(dot(a, a)); }
+// glam normalize: self * length().recip()
+template <int MODE> __device__ __forceinline__ v2 normalize(v2 a)
+{
+    if constexpr (MODE == 0) return a * (1.0f / length<0>(a));
+    else return a * __builtin_amdgcn_rsqf(dot(a, a));
+}
+template <int MODE> __device__ __forceinline__ v2 vdiv(v2 a, float s)
+{
+    if constexpr (MODE == 0) return mk(a.x / s, a.y / s);
+    else { float r = __builtin_amdgcn_rcpf(s); return mk(a.x * r, a.y * r); }
+}
+// glam normalize_or_zero (sfm.rs:199)
+__device__ __forceinline__ v2 normalize_or_zero(v2 a)
+{
+    float rcp = 1.0f / length<0>(a);
+    if (__builtin_isfinite(rcp) && rcp > 0.0f) return a * rcp;
+    return mk(0.0f, 0.0f);
+}
+
+// Rust `f32 as i32`: truncate toward zero, saturate, NaN -> 0
+__device__ __forceinline__ int32_t f32_as_i32(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+
+// ---- field sampling (util.rs:44-75, field.rs:235-258) -----------------------------
+struct FieldView {
+    const float* distance_map;
+    const float* const* potential_maps; // device array of device pointers
+    int32_t rows, cols;
+    float unit;
+    uint32_t n_maps;
+};
+
+// util.rs:30-36 + :53-56: texel or 1e12 when the index is negative / out of shape
+__device__ __forceinline__ float texel(const float* g, int32_t rows, int32_t cols, int64_t x,
+                                       int64_t y)
+{
+    if (x < 0 || y < 0 || y >= rows || x >= cols) return 1e12f;
+    return g[(size_t)y * (size_t)cols + (size_t)x];
+}
+
+// util.rs:44-58
+__device__ __forceinline__ float bilinear(const float* g, int32_t rows, int32_t cols, float px,
+                                          float py)
+{
+    float bx = __builtin_floorf(px), by = __builtin_floorf(py);
+    float tx = px - bx, ty = py - by;
+    float sx = 1.0f - tx, sy = 1.0f - ty;
+    int64_t ix = f32_as_i32(bx), iy = f32_as_i32(by);
+    float y = 0.0f;
+    y += sy * sx * texel(g, rows, cols, ix, iy);
+    y += sy * tx * texel(g, rows, cols, ix + 1, iy);
+    y += ty * sx * texel(g, rows, cols, ix, iy + 1);
+    y += ty * tx * texel(g, rows, cols, ix + 1, iy + 1);
+    return y;
+}
+
+// util.rs:61-75 (first digit = row offset, second = column offset)
+__device__ __forceinline__ v2 sobel(const float* g, int32_t rows, int32_t cols, float px, float py)
+{
+    float u00 = bilinear(g, rows, cols, px + -1.0f, py + -1.0f);
+    float u01 = bilinear(g, rows, cols, px + 0.0f, py + -1.0f);
+    float u02 = bilinear(g, rows, cols, px + 1.0f, py + -1.0f);
+    float u10 = bilinear(g, rows, cols, px + -1.0f, py + 0.0f);
+    float u12 = bilinear(g, rows, cols, px + 1.0f, py + 0.0f);
+    float u20 = bilinear(g, rows, cols, px + -1.0f, py + 1.0f);
+    float u21 = bilinear(g, rows, cols, px + 0.0f, py + 1.0f);
+    float u22 = bilinear(g, rows, cols, px + 1.0f, py + 1.0f);
+    return mk(u00 + u10 + u10 + u20 - u02 - u12 - u12 - u22,
+              u00 + u01 + u01 + u02 - u20 - u21 - u21 - u22);
+}
+
+// field.rs:236,243,250,256: position / unit - 0.5 (the division is IEEE in both modes:
+// it decides which texels are read)
+__device__ __forceinline__ v2 field_coord(const FieldView& f, v2 pos)
+{
+    return mk(pos.x / f.unit - 0.5f, pos.y / f.unit - 0.5f);
+}
+
+// ---- pair force (sfm.rs:131-153) -----------------------------------------------------
+#define PEDONI_COS_PHI (-0.17364817766693036f) /* sfm.rs:16 */
+
+template <int MODE>
+__device__ __forceinline__ void pair_force(v2 pos, v2 e, v2 pos_i, v2 vel_i, v2& acc,
+                                           const uint64_t* tab)
+{
+    v2 difference = pos - pos_i;                         // :131
+    float distance_squared = dot(difference, difference); // :132
+    if (distance_squared > 4.0f) return;                 // :133 (NaN falls through, as upstream)
+
+    float distance = fsqrt<MODE>(distance_squared);      // :137
+    v2 direction = difference * frcp<MODE>(distance);    // :138 normalize()
+
+    v2 t1 = difference - vel_i * 0.1f;                   // :141
+    float t1_length = length<MODE>(t1);                  // :142
+    float t2 = distance + t1_length;                     // :143
+    float vl = length<MODE>(vel_i) * 0.1f;
+    float b = fsqrt<MODE>(t2 * t2 - vl * vl) * 0.5f;     // :144
+
+    v2 nabla_b = vdiv<MODE>((direction + vdiv<MODE>(t1, t1_length)) * t2, 4.0f * b); // :146
+    float k = (2.1f / 0.3f) * fexp<MODE>(fdiv<MODE>(-b, 0.3f), tab);               // :147
+    v2 force = nabla_b * k;
+
+    if (dot(e, -force) < length<MODE>(force) * PEDONI_COS_PHI) // :149
+        force = force * 0.5f;                            // :150
+    acc = acc + force;                                   // :153
+}
+
+// util.rs:92-103
+__device__ __forceinline__ v2 distance_from_line(v2 point, v2 l0, v2 l1)
+{
+    v2 a = point - l0;
+    v2 b = l1 - l0;
+    float b_len2 = dot(b, b);
+    if (b_len2 == 0.0f) return a - l0;
+    float t = __builtin_fminf(__builtin_fmaxf(dot(a, b) / b_len2, 0.0f), 1.0f);
+    return a - b * t;
+}
+
+} // namespace pedoni

@@ -1,0 +1,393 @@
+// kernels.hpp -- gfx950 kernels of the per-timestep pedestrian update.
+//
+// Device-resident counterpart of SocialForceModel::spawn_pedestrians (sort/despawn half,
+// pedoni-simulator/src/models/sfm.rs:58-88) and ::update_states (sfm.rs:91-255).
+//
+// Data layout in HBM (structure of arrays, all fp32 / u32):
+//   pos[2][cap] float2, vel[2][cap] float2      ping-pong twice per tick (sort, integrate)
+//   desired_speed[2][cap] f32, destination[2][cap] u32   ping-pong once per tick (sort)
+//   key[cap] u32 (cell id or DEAD), rank[cap] u32 (arrival order in cell), slots[cap] u32
+//   cell_count[cells+1], cell_start[cells+1] u32 (= the reference's neighbor_grid_indices)
+//   field maps: distance_map + n potential maps, row-major (y, x) f32
+#pragma once
+
+#include "device_math.hpp"
+#include "pedoni_hip.h"
+
+namespace pedoni {
+
+using PedoniObstacleDev = ::PedoniObstacle;
+
+constexpr uint32_t DEAD = 0xffffffffu;
+
+struct GridView {
+    float unit;
+    int32_t rows, cols; // NeighborGrid.shape = (rows, cols) (neighbor_grid.rs:14-20)
+};
+
+// neighbor_grid.rs:27-29: (pos / unit).as_ivec2() then Index::index_checked
+__device__ __forceinline__ int64_t cell_of(const GridView& g, v2 pos)
+{
+    int32_t ix = f32_as_i32(pos.x / g.unit);
+    int32_t iy = f32_as_i32(pos.y / g.unit);
+    if (ix < 0 || iy < 0 || iy >= g.rows || ix >= g.cols) return -1;
+    return (int64_t)iy * g.cols + ix;
+}
+
+// field.rs:235-239 get_potential(dest, pos) > 0.25 (sfm.rs:69,82); a destination with no
+// map panics upstream (index out of bounds) -- here the agent is dropped instead.
+__device__ __forceinline__ bool survives(const FieldView& f, v2 pos, uint32_t dest)
+{
+    if (dest >= f.n_maps) return false;
+    v2 q = field_coord(f, pos);
+    return bilinear(f.potential_maps[dest], f.rows, f.cols, q.x, q.y) > 0.25f;
+}
+
+// ---- K_BIN ---------------------------------------------------------------------------
+// One thread per stored agent.  Slots [live, gap_end) hold agents despawned by earlier
+// ticks (the host only knows an upper bound of the live count) and are skipped.
+// Integer atomics make cell_count exact whatever the arrival order; the arrival rank is
+// only a provisional slot, K_REORDER restores the reference's order.
+__global__ void bin_kernel(const float2* __restrict__ pos, const uint32_t* __restrict__ dest,
+                           uint32_t n_total, const uint32_t* __restrict__ live_count,
+                           uint32_t gap_end, FieldView field, GridView grid, int32_t band_lo,
+                           int32_t band_hi, uint32_t* __restrict__ cell_count,
+                           uint32_t* __restrict__ key, uint32_t* __restrict__ rank)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    uint32_t live = *live_count;
+    uint32_t k = DEAD, r = 0;
+    if (i < live || i >= gap_end) {
+        float2 p = pos[i];
+        v2 pp = mk(p.x, p.y);
+        int64_t c = cell_of(grid, pp);
+        if (c >= 0 && survives(field, pp, dest[i])) {
+            int32_t row = (int32_t)(c / grid.cols);
+            // sharded runs keep only the band's rows plus one ghost row either side
+            if (row >= band_lo - 1 && row <= band_hi) {
+                k = (uint32_t)c;
+                r = atomicAdd(&cell_count[c], 1u);
+            }
+        }
+    }
+    key[i] = k;
+    rank[i] = r;
+}
+
+// no-grid variant (sfm.rs:78-88): survivors keep their order; key = 1/0 flag to be scanned
+__global__ void flag_kernel(const float2* __restrict__ pos, const uint32_t* __restrict__ dest,
+                            uint32_t n_total, const uint32_t* __restrict__ live_count,
+                            uint32_t gap_end, FieldView field, uint32_t* __restrict__ flag)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    uint32_t live = *live_count;
+    uint32_t a = 0;
+    if (i < live || i >= gap_end) {
+        float2 p = pos[i];
+        a = survives(field, mk(p.x, p.y), dest[i]) ? 1u : 0u;
+    }
+    flag[i] = a;
+}
+
+// ---- K_SCAN: exclusive prefix sum, 2048 elements per 256-thread block -----------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER_THREAD = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns exclusive prefix, sets total
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds_wave_sums,
+                                                         uint32_t& total)
+{
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) lds_wave_sums[wave] = inc;
+    __syncthreads();
+    uint32_t wave_off = 0, tot = 0;
+    int n_waves = blockDim.x >> 6;
+    for (int w = 0; w < n_waves; ++w) {
+        uint32_t s = lds_wave_sums[w];
+        if (w < wave) wave_off += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return wave_off + inc - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_reduce_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ block_sums)
+{
+    __shared__ uint32_t lds[SCAN_THREADS / 64];
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k)
+        if (base + k < n) s += in[base + k];
+    uint32_t total;
+    block_exclusive_scan(s, lds, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of block_sums in place; total -> *total_out (and a copy)
+__global__ void __launch_bounds__(1024)
+scan_top_kernel(uint32_t* __restrict__ block_sums, uint32_t n_blocks,
+                uint32_t* __restrict__ total_out, uint32_t* __restrict__ total_out2)
+{
+    __shared__ uint32_t lds[16];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_blocks; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < n_blocks ? block_sums[i] : 0;
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan(v, lds, total);
+        if (i < n_blocks) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        *total_out = carry;
+        if (total_out2) *total_out2 = carry;
+    }
+}
+
+// out[i] = exclusive prefix; optionally zero the input for the next tick
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_apply_kernel(uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ block_sums,
+                  uint32_t* __restrict__ out, int zero_input)
+{
+    __shared__ uint32_t lds[SCAN_THREADS / 64];
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+    uint32_t v[SCAN_PER_THREAD];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        v[k] = base + k < n ? in[base + k] : 0;
+        s += v[k];
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(s, lds, total) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        if (base + k < n) {
+            out[base + k] = ex;
+            if (zero_input) in[base + k] = 0;
+        }
+        ex += v[k];
+    }
+}
+
+// ---- K_SLOT --------------------------------------------------------------------------
+__global__ void slot_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ rank,
+                            uint32_t n_total, const uint32_t* __restrict__ cell_start,
+                            uint32_t* __restrict__ slots)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    uint32_t k = key[i];
+    if (k != DEAD) slots[cell_start[k] + rank[i]] = i;
+}
+
+// ---- K_REORDER -----------------------------------------------------------------------
+// sfm.rs:66-75 walks the cells row-major and each cell's list in insertion order, i.e. a
+// STABLE sort by cell id.  An agent's place inside its cell is the number of cell-mates
+// with a smaller previous index; the slot list gives those indices in arbitrary order.
+__global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t n_total,
+                               const uint32_t* __restrict__ cell_start,
+                               const uint32_t* __restrict__ slots,
+                               const float2* __restrict__ pos_in, const float2* __restrict__ vel_in,
+                               const float* __restrict__ v0_in, const uint32_t* __restrict__ dest_in,
+                               float2* __restrict__ pos_out, float2* __restrict__ vel_out,
+                               float* __restrict__ v0_out, uint32_t* __restrict__ dest_out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    uint32_t k = key[i];
+    if (k == DEAD) return;
+    uint32_t base = cell_start[k], end = cell_start[k + 1];
+    uint32_t before = 0;
+    for (uint32_t j = base; j < end; ++j) before += slots[j] < i ? 1u : 0u;
+    uint32_t p = base + before;
+    pos_out[p] = pos_in[i];
+    vel_out[p] = vel_in[i];
+    v0_out[p] = v0_in[i];
+    dest_out[p] = dest_in[i];
+}
+
+// no-grid compaction: survivor i goes to its exclusive flag prefix
+__global__ void compact_kernel(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ prefix,
+                               uint32_t n_total, const float2* __restrict__ pos_in,
+                               const float2* __restrict__ vel_in, const float* __restrict__ v0_in,
+                               const uint32_t* __restrict__ dest_in, float2* __restrict__ pos_out,
+                               float2* __restrict__ vel_out, float* __restrict__ v0_out,
+                               uint32_t* __restrict__ dest_out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total || !flag[i]) return;
+    uint32_t p = prefix[i];
+    pos_out[p] = pos_in[i];
+    vel_out[p] = vel_in[i];
+    v0_out[p] = v0_in[i];
+    dest_out[p] = dest_in[i];
+}
+
+// ---- K_FORCE -------------------------------------------------------------------------
+struct ForceArgs {
+    const float2* pos;   // sorted state (read)
+    const float2* vel;
+    const float* v0;
+    const uint32_t* dest;
+    float2* pos_out;     // integrated state (write); may be null for acc-only
+    float2* vel_out;
+    float2* acc_out;     // optional: accelerations only (no integration)
+    const uint32_t* live_count;
+    const uint32_t* cell_start;
+    const PedoniObstacleDev* obstacles;
+    uint32_t n_obstacles;
+    FieldView field;
+    GridView grid;
+    int32_t band_lo, band_hi; // rows whose agents are integrated (others are ghosts)
+    int32_t use_grid, use_distance_map;
+};
+
+// goal force, sfm.rs:106-109
+template <int MODE>
+__device__ __forceinline__ v2 goal_direction(const FieldView& f, v2 pos, uint32_t dest)
+{
+    v2 q = field_coord(f, pos);
+    v2 g = sobel(f.potential_maps[dest], f.rows, f.cols, q.x, q.y);
+    return normalize<MODE>(g);
+}
+
+// obstacle force from the distance map, sfm.rs:188-192
+template <int MODE>
+__device__ __forceinline__ v2 obstacle_force_map(const FieldView& f, v2 pos, const uint64_t* tab)
+{
+    v2 q = field_coord(f, pos);
+    float distance = bilinear(f.distance_map, f.rows, f.cols, q.x, q.y);
+    v2 direction = -normalize<MODE>(sobel(f.distance_map, f.rows, f.cols, q.x, q.y));
+    float k = (10.0f * 0.2f) * fexp<MODE>(fdiv<MODE>(-distance, 0.2f), tab);
+    return direction * k;
+}
+
+// obstacle force from explicit wall segments, sfm.rs:193-236
+template <int MODE>
+__device__ __forceinline__ v2 obstacle_force_segments(const PedoniObstacleDev* obs, uint32_t n_obs,
+                                                      v2 pos, const uint64_t* tab)
+{
+    v2 acc = mk(0.0f, 0.0f);
+    for (uint32_t o = 0; o < n_obs; ++o) {
+        v2 v0 = mk(obs[o].x0, obs[o].y0), v1 = mk(obs[o].x1, obs[o].y1);
+        float w = obs[o].width;
+        v2 d = v1 - v0;                                      // :197
+        float h = length<0>(d);                              // :198
+        v2 n = (normalize_or_zero(mk(d.y, -d.x)) * w) * 0.5f; // :199
+        v2 df[4];
+        df[0] = distance_from_line(pos, v0 + n, v0 - n);     // :200-209
+        df[1] = distance_from_line(pos, v1 + n, v1 - n);
+        df[2] = distance_from_line(pos, v0 + n, v1 + n);
+        df[3] = distance_from_line(pos, v0 - n, v1 - n);
+        float ds0 = length<0>(df[0]), ds1 = length<0>(df[1]);
+        float ds2 = length<0>(df[2]), ds3 = length<0>(df[3]);
+        if (ds0 < w && ds1 < w && ds2 < h && ds3 < h) continue; // :211-217
+        v2 dm = df[0]; float min_d = ds0;                    // :218-222 first minimum
+        if (ds1 < min_d) { min_d = ds1; dm = df[1]; }
+        if (ds2 < min_d) { min_d = ds2; dm = df[2]; }
+        if (ds3 < min_d) { min_d = ds3; dm = df[3]; }
+        v2 direction = normalize<MODE>(dm);                  // :223
+        float k = (10.0f * 0.2f) * fexp<MODE>(fdiv<MODE>(-min_d, 0.2f), tab); // :225
+        acc = acc + direction * k;                           // :226
+    }
+    return acc;
+}
+
+// v1 force kernel: one lane per agent, neighbours streamed from L1/L2 in the
+// reference's accumulation order (rows ascending, index ascending).
+template <int MODE>
+__global__ void force_kernel(ForceArgs a)
+{
+    __shared__ uint64_t tab[32];
+    if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
+    __syncthreads();
+
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = *a.live_count;
+    if (id >= n) return;
+
+    float2 p = a.pos[id], vv = a.vel[id];
+    v2 pos = mk(p.x, p.y), vel = mk(vv.x, vv.y);
+    float desired_speed = a.v0[id];
+    uint32_t destination = a.dest[id];
+
+    int32_t ix = 0, iy = 0;
+    if (a.use_grid) {
+        ix = f32_as_i32(pos.x / a.grid.unit);                // sfm.rs:113
+        iy = f32_as_i32(pos.y / a.grid.unit);
+        if (iy < a.band_lo || iy >= a.band_hi) {             // ghost row: never integrated
+            if (a.pos_out) {                                 // NaN position = "not mine"; the
+                float qn = __builtin_nanf("");               // next sort/despawn pass drops it
+                a.pos_out[id] = make_float2(qn, qn);
+                a.vel_out[id] = vv;
+            }
+            return;
+        }
+    }
+
+    v2 acc = mk(0.0f, 0.0f);                                 // :104
+    v2 e = goal_direction<MODE>(a.field, pos, destination);  // :107-108
+    acc = acc + vdiv<MODE>(e * desired_speed - vel, 0.5f);   // :109
+
+    if (a.use_grid) {                                        // :112-156
+        int32_t y_start = max(iy - 1, 0), y_end = min(iy + 1, a.grid.rows - 1);
+        int32_t x_start = max(ix - 1, 0), x_end = min(ix + 1, a.grid.cols - 1);
+        for (int32_t y = y_start; y <= y_end; ++y) {
+            int64_t offset = (int64_t)y * a.grid.cols;
+            uint32_t i_start = a.cell_start[offset + x_start];
+            uint32_t i_end = a.cell_start[offset + x_end + 1];
+            for (uint32_t i = i_start; i < i_end; ++i) {
+                if (i != id) {
+                    float2 pi = a.pos[i], vi = a.vel[i];
+                    pair_force<MODE>(pos, e, mk(pi.x, pi.y), mk(vi.x, vi.y), acc, tab);
+                }
+            }
+        }
+    } else {                                                 // :157-185
+        for (uint32_t i = 0; i < n; ++i) {
+            if (i != id) {
+                float2 pi = a.pos[i], vi = a.vel[i];
+                pair_force<MODE>(pos, e, mk(pi.x, pi.y), mk(vi.x, vi.y), acc, tab);
+            }
+        }
+    }
+
+    if (a.use_distance_map) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
+    else acc = acc + obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, tab);
+
+    if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); return; }
+
+    // integrator, sfm.rs:245-254
+    v2 vel_prev = vel;
+    vel = vel + acc * 0.1f;
+    float max_len = desired_speed * 1.3f;
+    float length_sq = dot(vel, vel);
+    if (length_sq > max_len * max_len) {                     // glam clamp_length_max
+        v2 q = vdiv<MODE>(vel, fsqrt<MODE>(length_sq));
+        vel = mk(max_len * q.x, max_len * q.y);
+    }
+    pos = pos + (vel + vel_prev) * 0.05f;
+    a.pos_out[id] = make_float2(pos.x, pos.y);
+    a.vel_out[id] = make_float2(vel.x, vel.y);
+}
+
+} // namespace pedoni

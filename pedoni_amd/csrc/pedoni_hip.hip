@@ -1,0 +1,893 @@
+// pedoni_hip.hip -- C ABI of the MI355X social-force backend (see include/pedoni_hip.h).
+//
+// Host orchestration of the device-resident tick.  One PedoniModel = one GPU's agents.
+// Nothing here falls back to a CPU implementation: without a HIP device every entry point
+// that would compute fails with PEDONI_E_NO_DEVICE / PEDONI_E_HIP.
+#include "pedoni_hip.h"
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pedoni;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(PEDONI_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+#define TRY(expr)                                                                            \
+    do {                                                                                     \
+        int rc_ = (expr);                                                                    \
+        if (rc_ != PEDONI_OK) return rc_;                                                    \
+    } while (0)
+
+const char* const KERNEL_NAMES[PEDONI_N_KERNELS] = {
+    "bin", "scan", "slot", "reorder", "force_integrate", "halo_pack", "halo_unpack", "other",
+};
+
+// ---- build-owned RNG (same specification as oracle/oracle_util.c) ----------------------
+// The reference draws desired speeds from the unseeded global fastrand generator
+// (sfm.rs:54), so there is no reference stream to follow: WyRand step, 24-bit f32,
+// Irwin-Hall(12) normal approximation.
+struct Rng {
+    uint64_t s;
+    uint64_t next()
+    {
+        s += 0xa0761d6478bd642fULL;
+        __uint128_t t = (__uint128_t)s * (__uint128_t)(s ^ 0xe7037ed1a0b428dbULL);
+        return (uint64_t)(t >> 64) ^ (uint64_t)t;
+    }
+    float f32() { return (float)(next() >> 40) * 0x1.0p-24f; }
+    float normal_approx(float mu, float sigma)
+    {
+        float acc = 0.0f;
+        for (int i = 0; i < 12; ++i) acc += f32();
+        return mu + sigma * (acc - 6.0f);
+    }
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kernel;
+};
+
+} // namespace
+
+struct PedoniModel {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    PedoniOptions opt{};
+    float size_x = 0, size_y = 0;
+    Rng rng{12345};
+
+    // field (field.rs:194-205)
+    FieldView field{};
+    float* d_distance_map = nullptr;
+    std::vector<float*> d_pot;
+    const float** d_pot_ptrs = nullptr;
+    PedoniObstacle* d_obstacles = nullptr;
+    uint32_t n_obstacles = 0;
+
+    // neighbor grid (neighbor_grid.rs)
+    GridView grid{};
+    uint32_t n_cells = 0;
+    int32_t band_lo = 0, band_hi = 0;
+
+    // agents
+    uint32_t cap = 0;
+    float2* d_pos[2] = {nullptr, nullptr};
+    float2* d_vel[2] = {nullptr, nullptr};
+    float* d_v0[2] = {nullptr, nullptr};
+    uint32_t* d_dest[2] = {nullptr, nullptr};
+    int pv = 0; // buffer holding current pos/vel
+    int vd = 0; // buffer holding current desired_speed/destination
+    uint32_t* d_key = nullptr;
+    uint32_t* d_rank = nullptr;
+    uint32_t* d_slots = nullptr;
+    uint32_t* d_scan_in = nullptr;  // cell_count (grid) or flags (no grid)
+    uint32_t* d_scan_out = nullptr; // cell_start (grid) or prefix (no grid)
+    uint32_t scan_cap = 0;
+    uint32_t* d_block_sums = nullptr;
+    uint32_t block_sums_cap = 0;
+    uint32_t* d_live = nullptr; // device: live agent count
+    uint32_t* h_pinned = nullptr;
+    float2* d_acc = nullptr;
+    uint32_t acc_cap = 0;
+
+    uint32_t n_upper = 0; // host upper bound of stored agents (live + stale + appended)
+    uint32_t gap_end = 0; // [live, gap_end) are stale slots, [gap_end, n_upper) appended
+    bool sorted = false;  // cell_start matches the current pos buffer
+
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    PedoniKernelTimes times{};
+};
+
+namespace {
+
+int bind(PedoniModel* m)
+{
+    if (!m) return fail(PEDONI_E_INVALID, "null model");
+    HIP_TRY(hipSetDevice(m->device));
+    return PEDONI_OK;
+}
+
+int drain_events(PedoniModel* m)
+{
+    if (m->ev_used == 0) return PEDONI_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (size_t i = 0; i < m->ev_used; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, m->ev_pool[i].a, m->ev_pool[i].b));
+        m->times.total_ms[m->ev_pool[i].kernel] += ms;
+        m->times.launches[m->ev_pool[i].kernel] += 1;
+    }
+    m->ev_used = 0;
+    return PEDONI_OK;
+}
+
+// RAII-less helper: records an event pair around a launch when profiling is on
+struct Timed {
+    PedoniModel* m;
+    EventPair* ep = nullptr;
+    int rc = PEDONI_OK;
+    Timed(PedoniModel* m_, int kernel) : m(m_)
+    {
+        if (!m->profiling) return;
+        if (m->ev_used == m->ev_pool.size()) {
+            if (m->ev_pool.size() >= 8192) {
+                rc = drain_events(m);
+                if (rc) return;
+            } else {
+                EventPair p{};
+                if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) {
+                    rc = fail(PEDONI_E_HIP, "hipEventCreate failed");
+                    return;
+                }
+                m->ev_pool.push_back(p);
+            }
+        }
+        ep = &m->ev_pool[m->ev_used++];
+        ep->kernel = kernel;
+        hipEventRecord(ep->a, m->stream);
+    }
+    ~Timed()
+    {
+        if (ep) hipEventRecord(ep->b, m->stream);
+    }
+};
+
+template <typename T> int dev_alloc(T** p, size_t n)
+{
+    HIP_TRY(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return PEDONI_OK;
+}
+
+int ensure_capacity(PedoniModel* m, uint32_t need)
+{
+    if (need <= m->cap) return PEDONI_OK;
+    uint64_t nc = std::max<uint64_t>(m->cap ? m->cap : 1024, 1024);
+    while (nc < need) nc *= 2;
+    if (nc > 0xfffffff0ull) return fail(PEDONI_E_INVALID, "agent capacity exceeds 2^32");
+    uint32_t ncap = (uint32_t)nc;
+
+    float2 *npos[2], *nvel[2];
+    float* nv0[2];
+    uint32_t* ndest[2];
+    for (int k = 0; k < 2; ++k) {
+        TRY(dev_alloc(&npos[k], ncap));
+        TRY(dev_alloc(&nvel[k], ncap));
+        TRY(dev_alloc(&nv0[k], ncap));
+        TRY(dev_alloc(&ndest[k], ncap));
+    }
+    if (m->n_upper) {
+        size_t n = m->n_upper;
+        HIP_TRY(hipMemcpyAsync(npos[m->pv], m->d_pos[m->pv], n * sizeof(float2),
+                               hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(nvel[m->pv], m->d_vel[m->pv], n * sizeof(float2),
+                               hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(nv0[m->vd], m->d_v0[m->vd], n * sizeof(float),
+                               hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(ndest[m->vd], m->d_dest[m->vd], n * sizeof(uint32_t),
+                               hipMemcpyDeviceToDevice, m->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (int k = 0; k < 2; ++k) {
+        hipFree(m->d_pos[k]); hipFree(m->d_vel[k]); hipFree(m->d_v0[k]); hipFree(m->d_dest[k]);
+        m->d_pos[k] = npos[k]; m->d_vel[k] = nvel[k]; m->d_v0[k] = nv0[k]; m->d_dest[k] = ndest[k];
+    }
+    hipFree(m->d_key); hipFree(m->d_rank); hipFree(m->d_slots);
+    TRY(dev_alloc(&m->d_key, ncap));
+    TRY(dev_alloc(&m->d_rank, ncap));
+    TRY(dev_alloc(&m->d_slots, ncap));
+    m->cap = ncap;
+
+    if (!m->opt.use_neighbor_grid) {
+        // the scan runs over per-agent flags
+        hipFree(m->d_scan_in); hipFree(m->d_scan_out); hipFree(m->d_block_sums);
+        m->scan_cap = ncap + 1;
+        TRY(dev_alloc(&m->d_scan_in, m->scan_cap));
+        TRY(dev_alloc(&m->d_scan_out, m->scan_cap));
+        m->block_sums_cap = (m->scan_cap + SCAN_TILE - 1) / SCAN_TILE + 1;
+        TRY(dev_alloc(&m->d_block_sums, m->block_sums_cap));
+    }
+    return PEDONI_OK;
+}
+
+// exclusive scan of d_scan_in[0..n) -> d_scan_out[0..n), total -> d_scan_out[n] and d_live
+int run_scan(PedoniModel* m, uint32_t n, int zero_input)
+{
+    Timed t(m, PEDONI_K_SCAN);
+    if (t.rc) return t.rc;
+    uint32_t n_blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (n_blocks == 0) n_blocks = 1;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream,
+                       m->d_scan_in, n, m->d_block_sums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, m->stream, m->d_block_sums,
+                       n_blocks, m->d_scan_out + n, m->d_live);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream,
+                       m->d_scan_in, n, m->d_block_sums, m->d_scan_out, zero_input);
+    HIP_TRY(hipGetLastError());
+    return PEDONI_OK;
+}
+
+inline uint32_t blocks_for(uint32_t n, uint32_t bs) { return std::max(1u, (n + bs - 1) / bs); }
+
+// sfm.rs:58-88 on the device
+int sort_despawn(PedoniModel* m)
+{
+    uint32_t n_total = m->n_upper;
+    const int src = m->pv, dst = 1 - m->pv, vsrc = m->vd, vdst = 1 - m->vd;
+    const uint32_t bs = 256;
+    if (n_total == 0) {
+        // nothing stored: live count 0, cell_start all zero
+        HIP_TRY(hipMemsetAsync(m->d_live, 0, sizeof(uint32_t), m->stream));
+        if (m->opt.use_neighbor_grid)
+            HIP_TRY(hipMemsetAsync(m->d_scan_out, 0, (size_t)(m->n_cells + 1) * sizeof(uint32_t),
+                                   m->stream));
+        m->sorted = true;
+        return PEDONI_OK;
+    }
+    if (m->opt.use_neighbor_grid) {
+        {
+            Timed t(m, PEDONI_K_BIN);
+            if (t.rc) return t.rc;
+            hipLaunchKernelGGL(bin_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0, m->stream,
+                               m->d_pos[src], m->d_dest[vsrc], n_total, m->d_live, m->gap_end,
+                               m->field, m->grid, m->band_lo, m->band_hi, m->d_scan_in, m->d_key,
+                               m->d_rank);
+        }
+        TRY(run_scan(m, m->n_cells, /*zero_input=*/1));
+        {
+            Timed t(m, PEDONI_K_SLOT);
+            if (t.rc) return t.rc;
+            hipLaunchKernelGGL(slot_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0, m->stream,
+                               m->d_key, m->d_rank, n_total, m->d_scan_out, m->d_slots);
+        }
+        {
+            Timed t(m, PEDONI_K_REORDER);
+            if (t.rc) return t.rc;
+            hipLaunchKernelGGL(reorder_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0,
+                               m->stream, m->d_key, n_total, m->d_scan_out, m->d_slots,
+                               m->d_pos[src], m->d_vel[src], m->d_v0[vsrc], m->d_dest[vsrc],
+                               m->d_pos[dst], m->d_vel[dst], m->d_v0[vdst], m->d_dest[vdst]);
+        }
+    } else {
+        {
+            Timed t(m, PEDONI_K_BIN);
+            if (t.rc) return t.rc;
+            hipLaunchKernelGGL(flag_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0, m->stream,
+                               m->d_pos[src], m->d_dest[vsrc], n_total, m->d_live, m->gap_end,
+                               m->field, m->d_scan_in);
+        }
+        // d_key keeps the flags: the scan may not zero what compact still reads
+        HIP_TRY(hipMemcpyAsync(m->d_key, m->d_scan_in, (size_t)n_total * sizeof(uint32_t),
+                               hipMemcpyDeviceToDevice, m->stream));
+        TRY(run_scan(m, n_total, /*zero_input=*/0));
+        {
+            Timed t(m, PEDONI_K_REORDER);
+            if (t.rc) return t.rc;
+            hipLaunchKernelGGL(compact_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0,
+                               m->stream, m->d_key, m->d_scan_out, n_total, m->d_pos[src],
+                               m->d_vel[src], m->d_v0[vsrc], m->d_dest[vsrc], m->d_pos[dst],
+                               m->d_vel[dst], m->d_v0[vdst], m->d_dest[vdst]);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    m->pv = dst;
+    m->vd = vdst;
+    m->gap_end = m->n_upper; // every stored agent is now either live (< *d_live) or stale
+    m->sorted = true;
+    return PEDONI_OK;
+}
+
+ForceArgs force_args(PedoniModel* m, float2* acc_out)
+{
+    ForceArgs a{};
+    a.pos = m->d_pos[m->pv];
+    a.vel = m->d_vel[m->pv];
+    a.v0 = m->d_v0[m->vd];
+    a.dest = m->d_dest[m->vd];
+    a.pos_out = acc_out ? nullptr : m->d_pos[1 - m->pv];
+    a.vel_out = acc_out ? nullptr : m->d_vel[1 - m->pv];
+    a.acc_out = acc_out;
+    a.live_count = m->d_live;
+    a.cell_start = m->d_scan_out;
+    a.obstacles = m->d_obstacles;
+    a.n_obstacles = m->n_obstacles;
+    a.field = m->field;
+    a.grid = m->grid;
+    a.band_lo = m->band_lo;
+    a.band_hi = m->band_hi;
+    a.use_grid = m->opt.use_neighbor_grid;
+    a.use_distance_map = m->opt.use_distance_map;
+    return a;
+}
+
+int launch_force(PedoniModel* m, float2* acc_out)
+{
+    uint32_t n = m->n_upper;
+    if (n == 0) return PEDONI_OK;
+    uint32_t bs = m->opt.gpu_work_size > 0 ? (uint32_t)m->opt.gpu_work_size : 256u;
+    ForceArgs a = force_args(m, acc_out);
+    Timed t(m, PEDONI_K_FORCE);
+    if (t.rc) return t.rc;
+    if (m->opt.math_mode == PEDONI_MATH_FAST)
+        hipLaunchKernelGGL(force_kernel<1>, dim3(blocks_for(n, bs)), dim3(bs), 0, m->stream, a);
+    else
+        hipLaunchKernelGGL(force_kernel<0>, dim3(blocks_for(n, bs)), dim3(bs), 0, m->stream, a);
+    HIP_TRY(hipGetLastError());
+    return PEDONI_OK;
+}
+
+// sfm.rs:91-255 on the device
+int update_states(PedoniModel* m)
+{
+    if (!m->sorted)
+        return fail(PEDONI_E_INVALID,
+                    "update_states needs the sort/despawn pass of spawn_pedestrians first "
+                    "(Simulator::tick order, lib.rs:85,90)");
+    TRY(launch_force(m, nullptr));
+    if (m->n_upper) m->pv = 1 - m->pv;
+    m->sorted = false;
+    return PEDONI_OK;
+}
+
+int sync_live_count(PedoniModel* m, uint32_t* out)
+{
+    HIP_TRY(hipMemcpyAsync(m->h_pinned, m->d_live, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    uint32_t live = m->h_pinned[0];
+    // tighten the host bound when nothing has been appended since the last pass
+    if (m->gap_end == m->n_upper) m->n_upper = m->gap_end = live;
+    *out = live;
+    return PEDONI_OK;
+}
+
+int append(PedoniModel* m, const float* pos_xy, const uint32_t* destination,
+           const float* desired_speed, const float* vel_xy, uint32_t n)
+{
+    if (n == 0) return PEDONI_OK;
+    if (!pos_xy || !destination) return fail(PEDONI_E_INVALID, "append: null pos/destination");
+    if ((uint64_t)m->n_upper + n > 0xfffffff0ull)
+        return fail(PEDONI_E_INVALID, "append: too many agents");
+    TRY(ensure_capacity(m, m->n_upper + n));
+    std::vector<float> v0(n);
+    if (desired_speed) std::memcpy(v0.data(), desired_speed, n * sizeof(float));
+    else for (uint32_t i = 0; i < n; ++i) v0[i] = m->rng.normal_approx(1.34f, 0.26f); // sfm.rs:54
+    size_t at = m->n_upper;
+    HIP_TRY(hipMemcpyAsync(m->d_pos[m->pv] + at, pos_xy, n * sizeof(float2), hipMemcpyHostToDevice,
+                           m->stream));
+    if (vel_xy)
+        HIP_TRY(hipMemcpyAsync(m->d_vel[m->pv] + at, vel_xy, n * sizeof(float2),
+                               hipMemcpyHostToDevice, m->stream));
+    else
+        HIP_TRY(hipMemsetAsync(m->d_vel[m->pv] + at, 0, n * sizeof(float2), m->stream)); // :53
+    HIP_TRY(hipMemcpyAsync(m->d_v0[m->vd] + at, v0.data(), n * sizeof(float), hipMemcpyHostToDevice,
+                           m->stream));
+    HIP_TRY(hipMemcpyAsync(m->d_dest[m->vd] + at, destination, n * sizeof(uint32_t),
+                           hipMemcpyHostToDevice, m->stream));
+    // pageable host buffers: the copies above are staged synchronously by the runtime, but
+    // v0 is a local -- make sure it has been consumed before it goes out of scope
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->n_upper += n;
+    m->sorted = false;
+    return PEDONI_OK;
+}
+
+} // namespace
+
+// =========================================================================================
+extern "C" {
+
+const char* pedoni_hip_last_error(void) { return g_last_error.c_str(); }
+
+const char* pedoni_hip_kernel_name(int32_t k)
+{
+    return (k >= 0 && k < PEDONI_N_KERNELS) ? KERNEL_NAMES[k] : "?";
+}
+
+void pedoni_hip_default_options(PedoniOptions* opt)
+{
+    if (!opt) return;
+    std::memset(opt, 0, sizeof(*opt));
+    opt->neighbor_grid_unit = 1.4f; // lib.rs:128
+    opt->field_grid_unit = 0.25f;   // lib.rs:129
+    opt->use_neighbor_grid = 1;     // lib.rs:130
+    opt->use_distance_map = 1;      // lib.rs:131
+    opt->gpu_work_size = 0;         // lib.rs:132 has 64; 0 = library default
+    opt->math_mode = PEDONI_MATH_EXACT;
+    opt->seed = 12345;
+    opt->initial_capacity = 0;
+}
+
+int pedoni_hip_device_count(int32_t* n)
+{
+    if (!n) return fail(PEDONI_E_INVALID, "null out");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(PEDONI_E_NO_DEVICE, hipGetErrorString(e)); }
+    *n = c;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
+                      const float* distance_map, const float* const* potential_maps,
+                      uint32_t n_maps, uint32_t field_rows, uint32_t field_cols, float field_unit,
+                      const PedoniObstacle* obstacles, uint32_t n_obstacles, int device,
+                      PedoniModel** out)
+{
+    if (!opt || !out) return fail(PEDONI_E_INVALID, "create: null options/out");
+    if (!distance_map || (n_maps && !potential_maps))
+        return fail(PEDONI_E_INVALID, "create: null field maps");
+    if (field_rows == 0 || field_cols == 0 || field_rows > 0x7fffffffu || field_cols > 0x7fffffffu)
+        return fail(PEDONI_E_INVALID, "create: bad field shape");
+    if (n_obstacles && !obstacles) return fail(PEDONI_E_INVALID, "create: null obstacles");
+    if (opt->gpu_work_size < 0 || opt->gpu_work_size > 1024 || (opt->gpu_work_size % 64) != 0)
+        return fail(PEDONI_E_INVALID, "create: gpu_work_size must be a multiple of 64 <= 1024");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return fail(PEDONI_E_NO_DEVICE, "create: no HIP device (this backend has no CPU fallback)");
+    if (device < 0 || device >= n_dev) return fail(PEDONI_E_INVALID, "create: bad device index");
+    HIP_TRY(hipSetDevice(device));
+
+    PedoniModel* m = new PedoniModel();
+    m->device = device;
+    m->opt = *opt;
+    m->size_x = size_x;
+    m->size_y = size_y;
+    m->rng.s = opt->seed;
+    *out = nullptr;
+
+    auto bail = [&](int rc) { pedoni_hip_destroy(m); return rc; };
+#define C_TRY(expr) do { int rc2_ = (expr); if (rc2_ != PEDONI_OK) return bail(rc2_); } while (0)
+#define C_HIP(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) return bail(fail(PEDONI_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e2_))); } while (0)
+
+    C_HIP(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+    m->stream = m->own_stream;
+
+    // field maps
+    size_t texels = (size_t)field_rows * field_cols;
+    C_TRY(dev_alloc(&m->d_distance_map, texels));
+    C_HIP(hipMemcpy(m->d_distance_map, distance_map, texels * sizeof(float), hipMemcpyHostToDevice));
+    m->d_pot.resize(n_maps, nullptr);
+    for (uint32_t k = 0; k < n_maps; ++k) {
+        if (!potential_maps[k]) return bail(fail(PEDONI_E_INVALID, "create: null potential map"));
+        C_TRY(dev_alloc(&m->d_pot[k], texels));
+        C_HIP(hipMemcpy(m->d_pot[k], potential_maps[k], texels * sizeof(float), hipMemcpyHostToDevice));
+    }
+    C_TRY(dev_alloc(&m->d_pot_ptrs, n_maps));
+    if (n_maps)
+        C_HIP(hipMemcpy(m->d_pot_ptrs, m->d_pot.data(), n_maps * sizeof(float*), hipMemcpyHostToDevice));
+    m->field.distance_map = m->d_distance_map;
+    m->field.potential_maps = m->d_pot_ptrs;
+    m->field.rows = (int32_t)field_rows;
+    m->field.cols = (int32_t)field_cols;
+    m->field.unit = field_unit;
+    m->field.n_maps = n_maps;
+
+    m->n_obstacles = n_obstacles;
+    C_TRY(dev_alloc(&m->d_obstacles, n_obstacles));
+    if (n_obstacles)
+        C_HIP(hipMemcpy(m->d_obstacles, obstacles, n_obstacles * sizeof(PedoniObstacle), hipMemcpyHostToDevice));
+
+    // neighbor grid, neighbor_grid.rs:14-20: shape = ceil(size / unit) as usize
+    if (opt->use_neighbor_grid) {
+        if (!(opt->neighbor_grid_unit > 0.0f))
+            return bail(fail(PEDONI_E_INVALID, "create: neighbor_grid_unit must be > 0"));
+        float fr = std::ceil(size_y / opt->neighbor_grid_unit);
+        float fc = std::ceil(size_x / opt->neighbor_grid_unit);
+        if (!(fr >= 1.0f) || !(fc >= 1.0f) || (double)fr * (double)fc > 1.0e9)
+            return bail(fail(PEDONI_E_INVALID, "create: neighbor grid shape out of range"));
+        m->grid.unit = opt->neighbor_grid_unit;
+        m->grid.rows = (int32_t)fr;
+        m->grid.cols = (int32_t)fc;
+        m->n_cells = (uint32_t)m->grid.rows * (uint32_t)m->grid.cols;
+        m->scan_cap = m->n_cells + 1;
+        C_TRY(dev_alloc(&m->d_scan_in, m->scan_cap));
+        C_TRY(dev_alloc(&m->d_scan_out, m->scan_cap));
+        C_HIP(hipMemset(m->d_scan_in, 0, (size_t)m->scan_cap * sizeof(uint32_t)));
+        C_HIP(hipMemset(m->d_scan_out, 0, (size_t)m->scan_cap * sizeof(uint32_t)));
+        m->block_sums_cap = (m->scan_cap + SCAN_TILE - 1) / SCAN_TILE + 1;
+        C_TRY(dev_alloc(&m->d_block_sums, m->block_sums_cap));
+    }
+    m->band_lo = 0;
+    m->band_hi = opt->use_neighbor_grid ? m->grid.rows : 0;
+
+    C_TRY(dev_alloc(&m->d_live, 4));
+    C_HIP(hipMemset(m->d_live, 0, 4 * sizeof(uint32_t)));
+    C_HIP(hipHostMalloc((void**)&m->h_pinned, 16 * sizeof(uint32_t), hipHostMallocDefault));
+    C_TRY(ensure_capacity(m, std::max<uint32_t>(opt->initial_capacity, 1024)));
+    C_HIP(hipDeviceSynchronize());
+#undef C_TRY
+#undef C_HIP
+    *out = m;
+    return PEDONI_OK;
+}
+
+void pedoni_hip_destroy(PedoniModel* m)
+{
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    for (auto& p : m->ev_pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (int k = 0; k < 2; ++k) {
+        hipFree(m->d_pos[k]); hipFree(m->d_vel[k]); hipFree(m->d_v0[k]); hipFree(m->d_dest[k]);
+    }
+    hipFree(m->d_key); hipFree(m->d_rank); hipFree(m->d_slots);
+    hipFree(m->d_scan_in); hipFree(m->d_scan_out); hipFree(m->d_block_sums);
+    hipFree(m->d_live); hipFree(m->d_acc);
+    if (m->h_pinned) hipHostFree(m->h_pinned);
+    hipFree(m->d_distance_map);
+    for (float* p : m->d_pot) hipFree(p);
+    hipFree((void*)m->d_pot_ptrs);
+    hipFree(m->d_obstacles);
+    if (m->own_stream) hipStreamDestroy(m->own_stream);
+    delete m;
+}
+
+int pedoni_hip_append(PedoniModel* m, const float* pos_xy, const uint32_t* destination,
+                      const float* desired_speed, const float* vel_xy, uint32_t n)
+{
+    TRY(bind(m));
+    return append(m, pos_xy, destination, desired_speed, vel_xy, n);
+}
+
+int pedoni_hip_sort_despawn(PedoniModel* m)
+{
+    TRY(bind(m));
+    return sort_despawn(m);
+}
+
+int pedoni_hip_spawn_pedestrians(PedoniModel* m, const PedoniPedestrian* peds, uint32_t n)
+{
+    TRY(bind(m));
+    if (n) {
+        if (!peds) return fail(PEDONI_E_INVALID, "spawn_pedestrians: null peds");
+        std::vector<float> pos(2 * (size_t)n);
+        std::vector<uint32_t> dest(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            pos[2 * i] = peds[i].x;
+            pos[2 * i + 1] = peds[i].y;
+            // sfm.rs:52 `p.destination as u32`
+            dest[i] = (uint32_t)peds[i].destination;
+        }
+        TRY(append(m, pos.data(), dest.data(), nullptr, nullptr, n));
+    }
+    return sort_despawn(m);
+}
+
+int pedoni_hip_update_states(PedoniModel* m)
+{
+    TRY(bind(m));
+    return update_states(m);
+}
+
+int pedoni_hip_tick_n(PedoniModel* m, uint32_t steps)
+{
+    TRY(bind(m));
+    for (uint32_t s = 0; s < steps; ++s) {
+        TRY(sort_despawn(m));
+        TRY(update_states(m));
+    }
+    return PEDONI_OK;
+}
+
+int pedoni_hip_tick(PedoniModel* m, PedoniStepMetrics* metrics)
+{
+    TRY(bind(m));
+    using clk = std::chrono::steady_clock;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    auto t0 = clk::now();
+    TRY(sort_despawn(m));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    auto t1 = clk::now();
+    hipEvent_t ea = nullptr, eb = nullptr;
+    HIP_TRY(hipEventCreate(&ea));
+    HIP_TRY(hipEventCreate(&eb));
+    HIP_TRY(hipEventRecord(ea, m->stream));
+    int rc = update_states(m);
+    hipEventRecord(eb, m->stream);
+    hipStreamSynchronize(m->stream);
+    auto t2 = clk::now();
+    float ms = -1.0f;
+    hipEventElapsedTime(&ms, ea, eb);
+    hipEventDestroy(ea);
+    hipEventDestroy(eb);
+    if (rc) return rc;
+    if (metrics) {
+        uint32_t live = 0;
+        TRY(sync_live_count(m, &live));
+        metrics->active_ped_count = (int32_t)live;                            // lib.rs:95
+        metrics->time_spawn = std::chrono::duration<double>(t1 - t0).count(); // lib.rs:86
+        metrics->time_calc_state = std::chrono::duration<double>(t2 - t1).count(); // lib.rs:91
+        metrics->time_calc_state_kernel = ms >= 0 ? ms * 1e-3 : -1.0;         // lib.rs:98 (None upstream)
+    }
+    return PEDONI_OK;
+}
+
+int pedoni_hip_get_pedestrian_count(PedoniModel* m, int32_t* count)
+{
+    TRY(bind(m));
+    if (!count) return fail(PEDONI_E_INVALID, "null count");
+    uint32_t live = 0;
+    TRY(sync_live_count(m, &live));
+    // agents appended since the last pass are part of `self.pedestrians` upstream too
+    *count = (int32_t)(live + (m->n_upper - m->gap_end));
+    return PEDONI_OK;
+}
+
+int pedoni_hip_download(PedoniModel* m, float* pos_xy, uint32_t* destination, float* vel_xy,
+                        float* desired_speed, uint32_t cap, uint32_t* n)
+{
+    TRY(bind(m));
+    uint32_t live = 0;
+    TRY(sync_live_count(m, &live));
+    uint32_t appended = m->n_upper - m->gap_end;
+    uint32_t total = live + appended;
+    if (n) *n = total;
+    // live agents [0, live) then appended agents [gap_end, n_upper)
+    uint32_t n1 = std::min(live, cap), n2 = std::min(appended, cap - n1);
+    auto copy = [&](void* dst, const void* src, size_t elem) -> int {
+        if (!dst) return PEDONI_OK;
+        if (n1) HIP_TRY(hipMemcpyAsync(dst, src, n1 * elem, hipMemcpyDeviceToHost, m->stream));
+        if (n2)
+            HIP_TRY(hipMemcpyAsync((char*)dst + (size_t)n1 * elem,
+                                   (const char*)src + (size_t)m->gap_end * elem, n2 * elem,
+                                   hipMemcpyDeviceToHost, m->stream));
+        return PEDONI_OK;
+    };
+    TRY(copy(pos_xy, m->d_pos[m->pv], sizeof(float2)));
+    TRY(copy(vel_xy, m->d_vel[m->pv], sizeof(float2)));
+    TRY(copy(desired_speed, m->d_v0[m->vd], sizeof(float)));
+    TRY(copy(destination, m->d_dest[m->vd], sizeof(uint32_t)));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return PEDONI_OK;
+}
+
+int pedoni_hip_list_pedestrians(PedoniModel* m, PedoniPedestrian* out, uint32_t cap, uint32_t* n)
+{
+    TRY(bind(m));
+    uint32_t total = 0;
+    TRY(pedoni_hip_download(m, nullptr, nullptr, nullptr, nullptr, 0, &total));
+    if (n) *n = total;
+    uint32_t k = std::min(total, cap);
+    if (!out || k == 0) return PEDONI_OK;
+    std::vector<float> pos(2 * (size_t)k);
+    std::vector<uint32_t> dest(k);
+    uint32_t got = 0;
+    TRY(pedoni_hip_download(m, pos.data(), dest.data(), nullptr, nullptr, k, &got));
+    for (uint32_t i = 0; i < k; ++i) {
+        out[i].x = pos[2 * i];
+        out[i].y = pos[2 * i + 1];
+        out[i].destination = dest[i];
+    }
+    return PEDONI_OK;
+}
+
+int pedoni_hip_clear(PedoniModel* m)
+{
+    TRY(bind(m));
+    HIP_TRY(hipMemsetAsync(m->d_live, 0, sizeof(uint32_t), m->stream));
+    if (m->opt.use_neighbor_grid)
+        HIP_TRY(hipMemsetAsync(m->d_scan_out, 0, (size_t)(m->n_cells + 1) * sizeof(uint32_t),
+                               m->stream));
+    m->n_upper = m->gap_end = 0;
+    m->sorted = false;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_neighbor_grid_indices(PedoniModel* m, uint32_t* out, uint32_t cap, uint32_t* len)
+{
+    TRY(bind(m));
+    if (!m->opt.use_neighbor_grid) { if (len) *len = 0; return PEDONI_OK; }
+    uint32_t n = m->n_cells + 1;
+    if (len) *len = n;
+    if (out && cap) {
+        HIP_TRY(hipMemcpyAsync(out, m->d_scan_out, (size_t)std::min(n, cap) * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    return PEDONI_OK;
+}
+
+int pedoni_hip_neighbor_grid_shape(PedoniModel* m, uint32_t* rows, uint32_t* cols)
+{
+    if (!m) return fail(PEDONI_E_INVALID, "null model");
+    if (rows) *rows = m->opt.use_neighbor_grid ? (uint32_t)m->grid.rows : 0;
+    if (cols) *cols = m->opt.use_neighbor_grid ? (uint32_t)m->grid.cols : 0;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_calc_accelerations(PedoniModel* m, float* acc_xy, uint32_t cap)
+{
+    TRY(bind(m));
+    if (!m->sorted) return fail(PEDONI_E_INVALID, "calc_accelerations needs a sorted state");
+    if (!acc_xy) return fail(PEDONI_E_INVALID, "null acc");
+    if (m->n_upper == 0) return PEDONI_OK;
+    if (m->acc_cap < m->n_upper) {
+        hipFree(m->d_acc);
+        m->d_acc = nullptr;
+        TRY(dev_alloc(&m->d_acc, m->cap));
+        m->acc_cap = m->cap;
+    }
+    TRY(launch_force(m, m->d_acc));
+    uint32_t live = 0;
+    TRY(sync_live_count(m, &live));
+    uint32_t k = std::min(live, cap);
+    if (k) HIP_TRY(hipMemcpy(acc_xy, m->d_acc, (size_t)k * sizeof(float2), hipMemcpyDeviceToHost));
+    return PEDONI_OK;
+}
+
+int pedoni_hip_set_stream(PedoniModel* m, void* hip_stream)
+{
+    TRY(bind(m));
+    TRY(drain_events(m));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->stream = hip_stream ? (hipStream_t)hip_stream : m->own_stream;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_get_stream(PedoniModel* m, void** hip_stream)
+{
+    if (!m || !hip_stream) return fail(PEDONI_E_INVALID, "null argument");
+    *hip_stream = (void*)m->stream;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_synchronize(PedoniModel* m)
+{
+    TRY(bind(m));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return PEDONI_OK;
+}
+
+int pedoni_hip_profile(PedoniModel* m, int32_t enable)
+{
+    TRY(bind(m));
+    TRY(drain_events(m));
+    m->profiling = enable != 0;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_kernel_times(PedoniModel* m, PedoniKernelTimes* out, int32_t reset)
+{
+    TRY(bind(m));
+    TRY(drain_events(m));
+    if (out) *out = m->times;
+    if (reset) m->times = PedoniKernelTimes{};
+    return PEDONI_OK;
+}
+
+// ---- sharding stubs are in halo.hip-less form: implemented below -----------------------
+int pedoni_hip_set_band(PedoniModel* m, int32_t row_begin, int32_t row_end)
+{
+    if (!m) return fail(PEDONI_E_INVALID, "null model");
+    if (!m->opt.use_neighbor_grid)
+        return fail(PEDONI_E_INVALID, "set_band: sharding needs the neighbor grid");
+    if (row_begin < 0 || row_end > m->grid.rows || row_begin >= row_end)
+        return fail(PEDONI_E_INVALID, "set_band: bad row range");
+    m->band_lo = row_begin;
+    m->band_hi = row_end;
+    m->sorted = false;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_halo_bytes(uint32_t cap_each, uint64_t* bytes)
+{
+    if (!bytes) return fail(PEDONI_E_INVALID, "null out");
+    *bytes = 2ull * (PEDONI_HALO_HEADER_WORDS + (uint64_t)cap_each * PEDONI_HALO_RECORD_WORDS) * 4ull;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_halo_pack(PedoniModel* m, void* send_dev, uint32_t cap_each)
+{
+    (void)send_dev; (void)cap_each;
+    TRY(bind(m));
+    return fail(PEDONI_E_INVALID, "halo_pack: not implemented yet");
+}
+
+int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const void* from_above_dev,
+                           uint32_t cap_each)
+{
+    (void)from_below_dev; (void)from_above_dev; (void)cap_each;
+    TRY(bind(m));
+    return fail(PEDONI_E_INVALID, "halo_unpack: not implemented yet");
+}
+
+int pedoni_hip_owned_count(PedoniModel* m, int32_t* count)
+{
+    return pedoni_hip_get_pedestrian_count(m, count);
+}
+
+// ---- device math self-test -----------------------------------------------------------------
+} // extern "C"
+
+namespace {
+template <int MODE>
+__global__ void selftest_kernel(int op, const float* a, const float* b, float* out, uint32_t n)
+{
+    __shared__ uint64_t tab[32];
+    if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (op) {
+    case 0: r = fdiv<MODE>(a[i], b[i]); break;
+    case 1: r = fsqrt<MODE>(a[i]); break;
+    case 2: r = fexp<MODE>(a[i], tab); break;
+    default: r = 0.0f;
+    }
+    out[i] = r;
+}
+} // namespace
+
+extern "C" int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mode, const float* a,
+                                        const float* b, float* out, uint32_t n)
+{
+    if (!a || !out || (op == 0 && !b) || op < 0 || op > 2)
+        return fail(PEDONI_E_INVALID, "selftest: bad arguments");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return fail(PEDONI_E_NO_DEVICE, "selftest: no HIP device");
+    HIP_TRY(hipSetDevice(device));
+    if (n == 0) return PEDONI_OK;
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void**)&da, n * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&db, n * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&dout, n * sizeof(float)));
+    HIP_TRY(hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice));
+    if (b) HIP_TRY(hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice));
+    if (math_mode == PEDONI_MATH_FAST)
+        hipLaunchKernelGGL(selftest_kernel<1>, dim3((n + 255) / 256), dim3(256), 0, 0, op, da, db, dout, n);
+    else
+        hipLaunchKernelGGL(selftest_kernel<0>, dim3((n + 255) / 256), dim3(256), 0, 0, op, da, db, dout, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dout);
+    return PEDONI_OK;
+}

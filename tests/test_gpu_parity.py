@@ -1,0 +1,312 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle.
+
+Bar (north_star): positions / velocities within 1e-5 relative fp32 per step from
+identical state.  PEDONI_MATH_EXACT is built to do better -- bit-identical -- so these
+tests assert 1e-5 everywhere and bit equality wherever the host libm agrees with the
+device's glibc-expf replay (checked first, on this machine).
+"""
+import ctypes
+import ctypes.util
+
+import numpy as np
+import pytest
+
+from helpers import (GOLDEN, bit_equal, box_scenario, inject_crowd, oracle_field,
+                     random_obstacle_scenario, rel_close)
+from pedoni_amd import scenario as scn
+
+pytestmark = pytest.mark.gpu
+
+
+def _libm_expf(x: np.ndarray) -> np.ndarray:
+    libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    libm.expf.restype = ctypes.c_float
+    libm.expf.argtypes = [ctypes.c_float]
+    return np.array([libm.expf(float(v)) for v in x], np.float32)
+
+
+def _make_hip(hip, sc, field, **opt):
+    options = hip.Options(**opt)
+    return hip.HipModel(options, sc.field.size, field.distance_map, field.potential_maps,
+                        field.unit, sc.obstacle_array())
+
+
+def _assert_state_equal(got, want, what, exact=True):
+    gp, gd, gv, g0 = got
+    wp, wd, wv, w0 = want
+    assert len(gp) == len(wp), f"{what}: survivor count {len(gp)} != {len(wp)}"
+    assert np.array_equal(gd, wd), f"{what}: destination order differs"
+    assert bit_equal(g0, w0).all(), f"{what}: desired_speed order differs"
+    for name, g, w in (("pos", gp, wp), ("vel", gv, wv)):
+        ok = rel_close(g, w)
+        assert ok.all(), f"{what}: {name} outside 1e-5 for {np.count_nonzero(~ok)} values"
+        if exact:
+            eq = bit_equal(g, w)
+            assert eq.all(), (f"{what}: {name} not bit-identical for {np.count_nonzero(~eq)} of "
+                              f"{eq.size} values (max |d| = {np.nanmax(np.abs(g - w)):.3e})")
+
+
+# ---- device arithmetic primitives -------------------------------------------------------
+def test_device_div_sqrt_are_ieee(hip):
+    rng = np.random.default_rng(1)
+    a = np.concatenate([rng.uniform(-10, 10, 50000), rng.lognormal(0, 20, 50000),
+                        [0.0, -0.0, 1e-40, 3e38, np.inf, np.nan]]).astype(np.float32)
+    b = np.concatenate([rng.uniform(-10, 10, 50000), rng.lognormal(0, 20, 50000),
+                        [0.0, 1.0, 1e-40, 1e-38, 2.0, 1.0]]).astype(np.float32)
+    from pedoni_amd import abi
+    with np.errstate(all="ignore"):
+        assert bit_equal(abi.selftest_math(0, a, b), a / b).all()
+        assert bit_equal(abi.selftest_math(1, np.abs(a)), np.sqrt(np.abs(a))).all()
+
+
+def test_device_exp_replays_host_libm(hip):
+    from pedoni_amd import abi
+    rng = np.random.default_rng(2)
+    x = np.concatenate([-rng.uniform(0, 30, 100000), -rng.lognormal(0, 3, 20000),
+                        [0.0, -0.0, -87.9, -88.1, -103.0, -104.5, -1e12, -np.inf, np.nan]]
+                       ).astype(np.float32)
+    got = abi.selftest_math(2, x)
+    want = _libm_expf(x)
+    eq = bit_equal(got, want)
+    assert eq.all(), f"device exp differs from host libm on {np.count_nonzero(~eq)} inputs: " \
+                     f"{x[~eq][:5]}"
+
+
+def test_fast_math_primitives_within_budget(hip):
+    from pedoni_amd import abi
+    rng = np.random.default_rng(3)
+    a = rng.uniform(0.01, 10, 100000).astype(np.float32)
+    b = rng.uniform(0.01, 10, 100000).astype(np.float32)
+    assert np.allclose(abi.selftest_math(0, a, b, abi.MATH_FAST), a / b, rtol=1e-6, atol=0)
+    assert np.allclose(abi.selftest_math(1, a, None, abi.MATH_FAST), np.sqrt(a), rtol=1e-6, atol=0)
+    x = -rng.uniform(0, 20, 100000).astype(np.float32)
+    assert np.allclose(abi.selftest_math(2, x, None, abi.MATH_FAST), np.exp(x.astype(np.float64)),
+                       rtol=5e-6, atol=0)
+
+
+# ---- C1: narrow-gap, 200 lock-step ticks ------------------------------------------------
+def test_narrow_gap_200_ticks_lockstep(hip, oracle):
+    sc = scn.load(GOLDEN / "scenarios" / "narrow_gap.toml")
+    field = oracle_field(oracle, sc)
+    rng = oracle.Rng(12345)
+    # Simulator::new (lib.rs:37-52): 50 agents on the origin waypoint's line
+    w = sc.waypoints[0].line
+    u = np.array([rng.f32() for _ in range(50)], np.float32)
+    p1, p2 = np.array(w[0], np.float32), np.array(w[1], np.float32)
+    pos = (p1[None, :] * (np.float32(1.0) - u)[:, None] + p2[None, :] * u[:, None]).astype(np.float32)
+    dest = np.ones(50, np.uint32)
+    v0 = np.array([rng.normal_approx(1.34, 0.26) for _ in range(50)], np.float32)
+
+    cpu = oracle.OracleModel(sc.field.size)
+    gpu = _make_hip(hip, sc, field)
+    cpu.spawn_pedestrians(field, pos, dest, v0, np.zeros((50, 2), np.float32))
+    gpu.append(pos, dest, v0, None)
+    gpu.sort_despawn()
+    _assert_state_equal(gpu.download(), cpu.download(), "after initial spawn")
+
+    counts = []
+    for step in range(200):
+        cpu.spawn_pedestrians(field)           # Simulator::tick, lib.rs:85 (empty spawn)
+        gpu.spawn_pedestrians()
+        assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices()), \
+            f"step {step}: neighbor_grid_indices differ"
+        _assert_state_equal(gpu.download(), cpu.download(), f"step {step} sorted")
+        cpu.update_states(field)               # lib.rs:90
+        gpu.update_states()
+        _assert_state_equal(gpu.download(), cpu.download(), f"step {step} integrated")
+        counts.append(gpu.get_pedestrian_count())
+    # plumbing check of SURVEY 8(d) C1: agents walk through the gap and despawn at the goal
+    assert counts[0] == 50 and counts[-1] < 50
+    gpu.close()
+
+
+# ---- C2-style: random obstacles, injected crowd, per step from identical state -----------
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 5000, 100_000])
+def test_random_crowd_per_step_parity(hip, oracle, n):
+    sc = random_obstacle_scenario(200.0, 300 if n < 100_000 else 1000)
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, n, 4, seed=100 + n)
+    cpu = oracle.OracleModel(sc.field.size)
+    gpu = _make_hip(hip, sc, field)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices())
+    _assert_state_equal(gpu.download(), cpu.download(), "sorted")
+    # accelerations alone (sfm.rs:93-241)
+    acc_g = gpu.calc_accelerations(cpu.get_pedestrian_count())
+    acc_c = cpu.calc_accelerations(field)
+    assert rel_close(acc_g, acc_c, floor=1e-2).all()
+    assert bit_equal(acc_g, acc_c).all()
+    for step in range(3):
+        cpu.update_states(field)
+        gpu.update_states()
+        _assert_state_equal(gpu.download(), cpu.download(), f"step {step} integrated")
+        cpu.spawn_pedestrians(field)
+        gpu.spawn_pedestrians()
+        assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices())
+        _assert_state_equal(gpu.download(), cpu.download(), f"step {step} sorted")
+    gpu.close()
+
+
+def test_empty_model(hip, oracle):
+    sc = box_scenario(40.0)
+    field = oracle_field(oracle, sc)
+    gpu = _make_hip(hip, sc, field)
+    gpu.spawn_pedestrians()
+    gpu.update_states()
+    gpu.spawn_pedestrians()
+    assert gpu.get_pedestrian_count() == 0
+    assert len(gpu.list_pedestrians()) == 0
+    assert not gpu.neighbor_grid_indices().any()
+    gpu.close()
+
+
+def test_out_of_grid_nan_and_goal_agents_vanish(hip, oracle):
+    """sfm.rs:66-74 + neighbor_grid.rs:27-33: agents outside the grid are never binned,
+    NaN positions fail `potential > 0.25`, agents on the goal line despawn."""
+    sc = box_scenario(40.0)
+    field = oracle_field(oracle, sc)
+    pos = np.array([[20, 20], [-3, 5], [5, -0.5], [41, 5], [5, 1e9], [np.nan, 5], [5, np.nan],
+                    [30.0, 20.0], [-0.5, 20.0], [10.05, 11.0], [39.9, 39.9]], np.float32)
+    dest = np.array([1, 1, 1, 1, 1, 1, 1, 0, 1, 0, 1], np.uint32)
+    v0 = np.full(len(pos), 1.3, np.float32)
+    vel = np.zeros_like(pos)
+    cpu = oracle.OracleModel(sc.field.size)
+    gpu = _make_hip(hip, sc, field)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    assert gpu.get_pedestrian_count() == cpu.get_pedestrian_count()
+    assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices())
+    _assert_state_equal(gpu.download(), cpu.download(), "sorted")
+    gpu.close()
+
+
+def test_coincident_agents_go_nan_then_despawn(hip, oracle):
+    """coincident agents give NaN forces; NaN agents survive the
+    integrator and are dropped by the next despawn pass."""
+    sc = box_scenario(40.0)
+    field = oracle_field(oracle, sc)
+    pos = np.array([[20, 20], [20, 20], [25, 25]], np.float32)
+    dest = np.ones(3, np.uint32)
+    v0 = np.full(3, 1.3, np.float32)
+    vel = np.zeros_like(pos)
+    cpu = oracle.OracleModel(sc.field.size)
+    gpu = _make_hip(hip, sc, field)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    cpu.update_states(field)
+    gpu.update_states()
+    _assert_state_equal(gpu.download(), cpu.download(), "integrated")
+    assert np.isnan(gpu.download()[0]).any()
+    cpu.spawn_pedestrians(field)
+    gpu.spawn_pedestrians()
+    assert gpu.get_pedestrian_count() == cpu.get_pedestrian_count() == 1
+    gpu.close()
+
+
+def test_many_agents_in_one_cell_keep_insertion_order(hip, oracle):
+    """Stable in-cell order (sfm.rs:67-68) with far more cell-mates than a wavefront."""
+    sc = box_scenario(40.0)
+    field = oracle_field(oracle, sc)
+    rng = np.random.default_rng(5)
+    n = 700
+    pos = (np.array([21.0, 21.0]) + rng.uniform(0.01, 1.3, (n, 2))).astype(np.float32)
+    dest = rng.integers(0, 2, n).astype(np.uint32)
+    v0 = rng.uniform(1, 1.6, n).astype(np.float32)
+    vel = rng.uniform(-0.5, 0.5, (n, 2)).astype(np.float32)
+    cpu = oracle.OracleModel(sc.field.size)
+    gpu = _make_hip(hip, sc, field)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    _assert_state_equal(gpu.download(), cpu.download(), "sorted")
+    cpu.update_states(field)
+    gpu.update_states()
+    _assert_state_equal(gpu.download(), cpu.download(), "integrated")
+    gpu.close()
+
+
+# ---- option paths ------------------------------------------------------------------------
+def test_no_neighbor_grid_bruteforce_path(hip, oracle):
+    """use_neighbor_grid = false: filter-only despawn (sfm.rs:78-88), O(N^2) pairs (:157-185)."""
+    sc = random_obstacle_scenario(60.0, 30)
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 1500, 4, seed=9)
+    pos[7] = [-4.0, 3.0]  # outside the field: potential is 1e12-ish -> survives upstream too
+    cpu = oracle.OracleModel(sc.field.size, use_neighbor_grid=False)
+    gpu = _make_hip(hip, sc, field, use_neighbor_grid=False)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    _assert_state_equal(gpu.download(), cpu.download(), "filtered")
+    for step in range(2):
+        cpu.update_states(field)
+        gpu.update_states()
+        _assert_state_equal(gpu.download(), cpu.download(), f"step {step}")
+        cpu.spawn_pedestrians(field)
+        gpu.spawn_pedestrians()
+    gpu.close()
+
+
+def test_explicit_wall_segment_path(hip, oracle):
+    """use_distance_map = false: sfm.rs:193-236 + util.rs:92-103 over every obstacle."""
+    sc = random_obstacle_scenario(80.0, 60)
+    sc.obstacles.append(scn.SegmentConfig(((40, 40), (40, 40)), 1.0))   # degenerate segment
+    sc.obstacles.append(scn.SegmentConfig(((30, 30), (50, 35)), 6.0))   # wide: agents inside
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 4000, 4, seed=11, clearance=0.0)
+    cpu = oracle.OracleModel(sc.field.size, use_distance_map=False)
+    gpu = _make_hip(hip, sc, field, use_distance_map=False)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    for step in range(2):
+        cpu.update_states(field, sc.obstacle_array())
+        gpu.update_states()
+        _assert_state_equal(gpu.download(), cpu.download(), f"step {step}")
+        cpu.spawn_pedestrians(field)
+        gpu.spawn_pedestrians()
+    gpu.close()
+
+
+def test_trait_spawn_draws_speeds_like_the_host_mirror(hip, oracle):
+    """spawn_pedestrians (trait form): velocity 0 and desired speed drawn inside the model
+    (sfm.rs:49-56) from the build-owned seeded generator."""
+    sc = box_scenario(40.0)
+    field = oracle_field(oracle, sc)
+    pos = np.array([[12, 12], [14, 20], [20, 30]], np.float32)
+    dest = np.array([1, 1, 1], np.uint32)
+    cpu = oracle.OracleModel(sc.field.size, seed=777)
+    gpu = _make_hip(hip, sc, field, seed=777)
+    cpu.spawn_pedestrians(field, pos, dest)
+    gpu.spawn_pedestrians(pos, dest)
+    _assert_state_equal(gpu.download(), cpu.download(), "spawned")
+    peds = gpu.list_pedestrians()
+    assert len(peds) == 3 and set(peds["destination"]) == {1}
+    gpu.close()
+
+
+def test_fast_math_mode_within_1e5(hip, oracle):
+    """PEDONI_MATH_FAST: hardware rcp/rsq/exp; 1e-5 relative per step except agents whose
+    discrete decisions (cutoff, field-of-view halving, speed clamp) sit on a boundary."""
+    sc = random_obstacle_scenario(200.0, 300)
+    field = oracle_field(oracle, sc)
+    n = 50_000
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, n, 4, seed=21)
+    from pedoni_amd import abi
+    cpu = oracle.OracleModel(sc.field.size)
+    gpu = _make_hip(hip, sc, field, math_mode=abi.MATH_FAST)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    cpu.update_states(field)
+    gpu.update_states()
+    gp, gd, gv, g0 = gpu.download()
+    wp, wd, wv, w0 = cpu.download()
+    assert np.array_equal(gd, wd)
+    bad = ~(rel_close(gp, wp).all(axis=1) & rel_close(gv, wv).all(axis=1))
+    assert bad.mean() < 2e-4, f"{bad.sum()} of {n} agents outside 1e-5 in fast mode"
+    gpu.close()
