@@ -1,0 +1,181 @@
+// simulator.cpp -- Simulator / SocialForceModelHip (pedoni-simulator/src/lib.rs,
+// models/mod.rs) over the C-ABI of include/pedoni_hip.h.
+#include "pedoni_host.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <stdexcept>
+
+namespace pedoni_host {
+
+// ---- build-owned RNG: WyRand step, 24-bit f32, 53-bit f64 (same spec as the HIP library's
+// desired-speed generator; the reference's fastrand global is never seeded) ----------------
+uint64_t Rng::next()
+{
+    state += 0xa0761d6478bd642fULL;
+    __uint128_t t = (__uint128_t)state * (__uint128_t)(state ^ 0xe7037ed1a0b428dbULL);
+    return (uint64_t)(t >> 64) ^ (uint64_t)t;
+}
+float Rng::f32() { return (float)(next() >> 40) * 0x1.0p-24f; }
+double Rng::f64() { return (double)(next() >> 11) * 0x1.0p-53; }
+int32_t Rng::poisson(double lambda) // util.rs:78-89
+{
+    int32_t y = 0;
+    double x = f64();
+    const double exp_lambda = std::exp(-lambda);
+    while (x >= exp_lambda) {
+        x *= f64();
+        y += 1;
+    }
+    return y;
+}
+
+namespace {
+
+void check(int rc, const char* what)
+{
+    if (rc != PEDONI_OK)
+        throw std::runtime_error(std::string(what) + ": " + pedoni_hip_last_error());
+}
+
+// glam 0.29 Vec2::lerp: self * (1 - s) + rhs * s   (lib.rs:43,76)
+Vec2 lerp(Vec2 a, Vec2 b, float s)
+{
+    const float k = 1.0f - s;
+    return Vec2{a.x * k + b.x * s, a.y * k + b.y * s};
+}
+
+} // namespace
+
+// ---- SocialForceModelHip -------------------------------------------------------------------
+SocialForceModelHip::SocialForceModelHip(const SimulatorOptions& options, const Scenario& scenario,
+                                         const Field& field)
+{
+    PedoniOptions o;
+    pedoni_hip_default_options(&o);
+    o.neighbor_grid_unit = options.neighbor_grid_unit;
+    o.field_grid_unit = options.field_grid_unit;
+    o.use_neighbor_grid = options.use_neighbor_grid;
+    o.use_distance_map = options.use_distance_map;
+    // lib.rs:132 default 64 is an OpenCL local size; any multiple of 64 is honoured here
+    o.gpu_work_size = (options.gpu_work_size % 64 == 0 && options.gpu_work_size <= 1024)
+                          ? (int32_t)options.gpu_work_size : 0;
+    o.math_mode = options.math_mode;
+    o.seed = options.seed ^ 0x5eedULL; // desired-speed stream, distinct from the spawn stream
+
+    std::vector<const float*> maps;
+    for (const auto& pm : field.potential_maps) maps.push_back(pm.data());
+    std::vector<PedoniObstacle> obs;
+    for (const ObstacleConfig& c : scenario.obstacles)
+        obs.push_back(PedoniObstacle{c.line[0].x, c.line[0].y, c.line[1].x, c.line[1].y, c.width});
+    check(pedoni_hip_create(&o, scenario.field.size.x, scenario.field.size.y,
+                            field.distance_map.data(), maps.data(), (uint32_t)maps.size(),
+                            (uint32_t)field.rows, (uint32_t)field.cols, field.unit, obs.data(),
+                            (uint32_t)obs.size(), options.device, &model_),
+          "SocialForceModelHip::new");
+}
+
+SocialForceModelHip::~SocialForceModelHip() { pedoni_hip_destroy(model_); }
+
+void SocialForceModelHip::spawn_pedestrians(const Field&, std::vector<Pedestrian> new_pedestrians)
+{
+    std::vector<PedoniPedestrian> peds(new_pedestrians.size());
+    for (size_t i = 0; i < peds.size(); ++i)
+        peds[i] = PedoniPedestrian{new_pedestrians[i].pos.x, new_pedestrians[i].pos.y,
+                                   (uint64_t)new_pedestrians[i].destination};
+    check(pedoni_hip_spawn_pedestrians(model_, peds.data(), (uint32_t)peds.size()),
+          "spawn_pedestrians");
+}
+
+void SocialForceModelHip::update_states(const Scenario&, const Field&)
+{
+    check(pedoni_hip_update_states(model_), "update_states");
+}
+
+std::vector<Pedestrian> SocialForceModelHip::list_pedestrians() const
+{
+    uint32_t n = 0;
+    check(pedoni_hip_list_pedestrians(model_, nullptr, 0, &n), "list_pedestrians");
+    std::vector<PedoniPedestrian> raw(n);
+    check(pedoni_hip_list_pedestrians(model_, raw.data(), n, &n), "list_pedestrians");
+    std::vector<Pedestrian> out(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        out[i].pos = Vec2{raw[i].x, raw[i].y};
+        out[i].destination = (size_t)raw[i].destination;
+    }
+    return out;
+}
+
+int32_t SocialForceModelHip::get_pedestrian_count() const
+{
+    int32_t c = 0;
+    check(pedoni_hip_get_pedestrian_count(model_, &c), "get_pedestrian_count");
+    return c;
+}
+
+// ---- Simulator -------------------------------------------------------------------------------
+Simulator::Simulator(SimulatorOptions options_, Scenario scenario_)
+    : options(options_), scenario(std::move(scenario_))
+{
+    rng_.state = options.seed;
+    for (const PedestrianConfig& p : scenario.pedestrians)
+        if (p.origin >= scenario.waypoints.size() || p.destination >= scenario.waypoints.size())
+            throw std::runtime_error("Simulator::new: pedestrian origin/destination out of range");
+
+    field = Field::from_scenario(scenario, options.field_grid_unit);        // lib.rs:30
+
+    switch (options.backend) {                                              // lib.rs:32-35
+    case Backend::Hip:
+        model = std::make_unique<SocialForceModelHip>(options, scenario, field);
+        break;
+    case Backend::Cpu:
+        throw std::runtime_error("Backend::Cpu (the reference's SocialForceModel) is not part of "
+                                 "this build; use Backend::Hip");
+    case Backend::Gpu:
+        throw std::runtime_error("Backend::Gpu (the reference's OpenCL model) is not part of "
+                                 "this build; use Backend::Hip");
+    }
+
+    std::vector<Pedestrian> new_pedestrians;                                // lib.rs:37-51
+    for (const PedestrianConfig& p : scenario.pedestrians) {
+        if (p.spawn.kind != PedestrianSpawnConfig::Once) continue;
+        const Vec2 p1 = scenario.waypoints[p.origin].line[0], p2 = scenario.waypoints[p.origin].line[1];
+        for (int32_t k = 0; k < p.spawn.count; ++k)
+            new_pedestrians.push_back(Pedestrian{lerp(p1, p2, rng_.f32()), p.destination});
+    }
+    model->spawn_pedestrians(field, std::move(new_pedestrians));           // lib.rs:52
+}
+
+StepMetrics Simulator::tick()
+{
+    using clk = std::chrono::steady_clock;
+    step += 1;                                                              // lib.rs:65
+
+    auto instant = clk::now();                                              // lib.rs:68
+    std::vector<Pedestrian> new_pedestrians;
+    for (const PedestrianConfig& p : scenario.pedestrians) {                // lib.rs:70-84
+        if (p.spawn.kind != PedestrianSpawnConfig::Periodic) continue;
+        const Vec2 p1 = scenario.waypoints[p.origin].line[0], p2 = scenario.waypoints[p.origin].line[1];
+        const int32_t count = rng_.poisson(p.spawn.frequency / 10.0);
+        for (int32_t k = 0; k < count; ++k)
+            new_pedestrians.push_back(Pedestrian{lerp(p1, p2, rng_.f32()), p.destination});
+    }
+    model->spawn_pedestrians(field, std::move(new_pedestrians));           // lib.rs:85
+    auto* hip = dynamic_cast<SocialForceModelHip*>(model.get());
+    if (hip) pedoni_hip_synchronize(hip->handle());  // the launches are asynchronous
+    const double time_spawn = std::chrono::duration<double>(clk::now() - instant).count();
+
+    instant = clk::now();                                                   // lib.rs:89
+    model->update_states(scenario, field);                                  // lib.rs:90
+    if (hip) pedoni_hip_synchronize(hip->handle());
+    const double time_calc_state = std::chrono::duration<double>(clk::now() - instant).count();
+
+    StepMetrics m;                                                          // lib.rs:94-99
+    m.active_ped_count = model->get_pedestrian_count();
+    m.time_spawn = time_spawn;
+    m.time_calc_state = time_calc_state;
+    m.time_calc_state_kernel = std::nullopt; // upstream: always None (lib.rs:98)
+    return m;
+}
+
+} // namespace pedoni_host
