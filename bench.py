@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-steps/s of the per-timestep pedestrian update on MI355X.
+
+Workload (BASELINE.json `metric`: "agent-steps/sec at N=1e6"; configs[2]):
+a synthetic uniform crowd of 1e6 agents per GPU in a sparse.toml-style box at 1 agent/m^2
+(1000 m x 1000 m per GPU; with G GPUs the box is 1000 m x G*1000 m and is cut into G row
+bands -- weak scaling, per-GPU work fixed), default SimulatorOptions (neighbor grid 1.4 m,
+distance/potential maps at 0.25 m built by the product's own Field::from_scenario), all
+agents heading for the right-hand waypoint.  One "step" = one Simulator::tick of the hot
+path: sort/despawn pass (spawn_pedestrians with no new agents) + update_states.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `value` is whole-job agent-steps/s with the state
+resident in HBM; `roofline` prices the dominant kernel (force + integrate) at its
+algorithmic 40 B/agent against 8 TB/s; `cpu_baseline` times the CPU oracle (a C port of
+the reference's Rust/rayon path -- the Rust binary cannot be built here) on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+AGENTS_PER_GPU = 1_000_000
+DENSITY = 1.0                      # agents / m^2
+BYTES_FORCE = 40                   # 24 B read + 16 B written per agent
+BYTES_TICK = 88                    # + sort/reorder pass 24 R + 24 W
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def box_geometry(width: float, height: float, wall_w: float = 0.2, margin: float = 10.0):
+    """sparse.toml-style box: 4 thin border walls, waypoint lines `margin` m inside the
+    left / right edges.  Rows of (x0, y0, x1, y1, width)."""
+    obstacles = np.array([[0, 0, 0, height, wall_w], [width, 0, width, height, wall_w],
+                          [0, 0, width, 0, wall_w], [0, height, width, height, wall_w]], np.float32)
+    waypoints = np.array([[margin, margin, margin, height - margin, 1.0],
+                          [width - margin, margin, width - margin, height - margin, 1.0]], np.float32)
+    return obstacles, waypoints
+
+
+def uniform_crowd(n: int, x_range, y_range, seed: int):
+    """Seeded synthetic crowd: positions uniform in the rectangle, destination = right
+    waypoint, v0 ~ N(1.34, 0.26) clipped to [0.5, 2.2], velocity = 0.5 * v0 along +x."""
+    rng = np.random.default_rng(seed)
+    pos = np.empty((n, 2), np.float32)
+    pos[:, 0] = rng.uniform(x_range[0], x_range[1], n)
+    pos[:, 1] = rng.uniform(y_range[0], y_range[1], n)
+    dest = np.ones(n, np.uint32)
+    v0 = np.clip(rng.normal(1.34, 0.26, n), 0.5, 2.2).astype(np.float32)
+    vel = np.zeros((n, 2), np.float32)
+    vel[:, 0] = 0.5 * v0
+    return pos, dest, v0, vel
+
+
+def cpu_baseline(size, field, obstacles, pos, dest, v0, vel, budget_s: float = 20.0):
+    """Time the CPU oracle (oracle/, C port of the reference's CPU path with its parallel
+    structure: serial sort/despawn, parallel-for accelerations, serial integrator) on a
+    bounded sample of the SAME workload.  Checker code, used here only as the baseline."""
+    from oracle import pyoracle
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    ofield = pyoracle.Field(field.unit, field.distance_map, field.potential_maps)
+    m = pyoracle.OracleModel(size, threads=cores)
+    m.spawn_pedestrians(ofield, pos, dest, v0, vel)
+    steps, t_used = 0, 0.0
+    t0 = time.perf_counter()
+    m.update_states(ofield, obstacles)       # first step (also warms caches)
+    m.spawn_pedestrians(ofield)
+    per = time.perf_counter() - t0
+    n_steps = int(max(2, min(400, budget_s / max(per, 1e-3))))
+    t0 = time.perf_counter()
+    agents = 0
+    for _ in range(n_steps):
+        agents += m.get_pedestrian_count()
+        m.update_states(ofield, obstacles)
+        m.spawn_pedestrians(ofield)
+        steps += 1
+    t_used = time.perf_counter() - t0
+    return {
+        "value": agents / t_used, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+        "sample": f"{steps} ticks of the same {len(pos)}-agent crowd and field "
+                  f"({t_used:.1f} s; C port of pedoni's SocialForceModel CPU path with OpenMP where "
+                  "upstream uses rayon -- the Rust binary cannot be built here)",
+    }
+
+
+def pmc_traffic(workload: str):
+    """HBM bytes per force-kernel launch from the committed rocprofv3 --pmc passes
+    (profiles/*pmc*.json written by tools/pmc_summary.py), or None."""
+    best = None
+    for p in sorted((ROOT / "profiles").glob("*pmc*.json")):
+        try:
+            d = json.loads(p.read_text())
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("kernel", "").startswith("force"):
+            best = d.get("hbm_bytes_per_launch")
+    return best
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--agents-per-gpu", type=int, default=AGENTS_PER_GPU)
+    ap.add_argument("--math", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--work-size", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-profile", action="store_true",
+                    help="skip the per-kernel hipEvent pairs in the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
+                     "(one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    from pedoni_amd import abi, host
+
+    if not torch.cuda.is_available() or abi.device_count() < 1:
+        sys.exit("bench.py needs a HIP device: the backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    G = args.gpus
+    n_per = args.agents_per_gpu
+    side = float(np.sqrt(n_per / DENSITY))          # 1000 m at 1e6 agents
+    width, height = side, side * G
+    obstacles, waypoints = box_geometry(width, height)
+    workload = (f"uniform crowd N={n_per * G:.0e} ({n_per:.0e}/GPU) in a {width:.0f}x{height:.0f} m box, "
+                f"rho={DENSITY:g}/m^2, neighbor grid 1.4 m, field maps 0.25 m, fp32").replace("e+0", "e")
+
+    t0 = time.perf_counter()
+    field = host.Field.build((width, height), 0.25, obstacles, waypoints)
+    t_field = time.perf_counter() - t0
+
+    opt = abi.Options(math_mode=abi.MATH_FAST if args.math == "fast" else abi.MATH_EXACT,
+                      gpu_work_size=args.work_size, initial_capacity=int(n_per * 1.3))
+    model = abi.HipModel(opt, (width, height), field.distance_map, field.potential_maps,
+                         field.unit, obstacles, device=local_rank)
+
+    # this rank's agents: its own 1000 m band (2 m clear of the outer walls)
+    y_lo, y_hi = side * rank, side * (rank + 1)
+    pos, dest, v0, vel = uniform_crowd(
+        n_per, (12.0, width - 12.0), (max(y_lo, 2.0), min(y_hi, height - 2.0)), seed=12345 + rank)
+
+    if G > 1:
+        from pedoni_amd.sharded import ShardedModel
+        runner = ShardedModel(model, rank, G, dist, torch, expected_row_agents=int(width * 1.4 * DENSITY))
+        runner.load(pos, dest, v0, vel)
+        step_fn = runner.tick_n
+    else:
+        model.append(pos, dest, v0, vel)
+        step_fn = model.tick_n
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step_fn(args.warmup)
+    barrier()
+    n_before = model.owned_count() if G > 1 else model.get_pedestrian_count()
+    if not args.no_profile:
+        model.profile(True)
+        model.kernel_times(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    step_fn(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = model.kernel_times() if not args.no_profile else {}
+    model.profile(False)
+    n_after = model.owned_count() if G > 1 else model.get_pedestrian_count()
+
+    agents_local = 0.5 * (n_before + n_after)       # despawns during the run are negligible
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        a = torch.tensor([agents_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        agents_total = float(a.item())
+    else:
+        agents_total = agents_local
+
+    if rank == 0:
+        value = agents_total * args.steps / elapsed
+        out = {
+            "metric": "agent-steps/sec at N=1e6; achieved HBM GB/s vs roofline; 1/2/4/8-GPU scaling",
+            "value": value, "unit": "agent-steps/s", "n_gpus": G, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload, "agents_total": int(round(agents_total)),
+                       "math_mode": args.math, "parallelism": f"row-bands x{G}" if G > 1 else "single GPU",
+                       "field_build_s": round(t_field, 2),
+                       "tick_algorithmic_GBps": BYTES_TICK * value / 1e9},
+        }
+        fk = ktimes.get("force_integrate")
+        if fk and fk["launches"]:
+            avg_ms = fk["total_ms"] / fk["launches"]
+            achieved = BYTES_FORCE * agents_local / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(workload),
+                "kernel": "force_integrate", "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_launch": BYTES_FORCE * agents_local,
+            }
+            out["kernel_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in ktimes.items()
+                                         if v["launches"]}
+        else:
+            out["roofline"] = None
+        if G == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline((width, height), field, obstacles, pos, dest, v0, vel,
+                                               args.cpu_budget)
+        print(json.dumps(out), flush=True)
+
+    model.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -283,10 +283,11 @@ __device__ __forceinline__ v2 obstacle_force_map(const FieldView& f, v2 pos, con
 
 // obstacle force from explicit wall segments, sfm.rs:193-236
 template <int MODE>
-__device__ __forceinline__ v2 obstacle_force_segments(const PedoniObstacleDev* obs, uint32_t n_obs,
-                                                      v2 pos, const uint64_t* tab)
+__device__ __forceinline__ void obstacle_force_segments(const PedoniObstacleDev* obs, uint32_t n_obs,
+                                                        v2 pos, v2& acc, const uint64_t* tab)
 {
-    v2 acc = mk(0.0f, 0.0f);
+    // accumulates straight into the agent's running `acc`: fp addition order is part of
+    // the result (sfm.rs:226 `acc += force` once per obstacle)
     for (uint32_t o = 0; o < n_obs; ++o) {
         v2 v0 = mk(obs[o].x0, obs[o].y0), v1 = mk(obs[o].x1, obs[o].y1);
         float w = obs[o].width;
@@ -309,7 +310,6 @@ __device__ __forceinline__ v2 obstacle_force_segments(const PedoniObstacleDev* o
         float k = (10.0f * 0.2f) * fexp<MODE>(fdiv<MODE>(-min_d, 0.2f), tab); // :225
         acc = acc + direction * k;                           // :226
     }
-    return acc;
 }
 
 // v1 force kernel: one lane per agent, neighbours streamed from L1/L2 in the
@@ -372,7 +372,7 @@ __global__ void force_kernel(ForceArgs a)
     }
 
     if (a.use_distance_map) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
-    else acc = acc + obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, tab);
+    else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
 
     if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); return; }
 
