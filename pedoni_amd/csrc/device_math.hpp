@@ -174,6 +174,84 @@ __device__ __forceinline__ v2 sobel(const float* g, int32_t rows, int32_t cols, 
               u00 + u01 + u01 + u02 - u20 - u21 - u21 - u22);
 }
 
+// ---- shared-patch sampling ---------------------------------------------------------------
+// util::sobel_filter takes 8 bilinear samples at p + (+-1 | 0, +-1 | 0); with the centre
+// sample of get_obstacle_distance that is a 3 x 3 stencil of bilinear taps whose texels
+// all lie in one 4 x 4 patch.  The reference recomputes floor / fraction / 4 gathers per
+// tap; here the three per-axis (floor, fraction) sets are computed once -- with the very
+// same fp32 operations, so every tap value is bit-identical -- and the 16 texels are
+// loaded once.  If rounding of p +- 1 moves a tap's floor off the patch (or p is NaN /
+// huge), the literal per-tap path below is used instead.
+struct AxisTaps {
+    float s[3], t[3]; // weights of the tap at offset -1, 0, +1
+    int32_t i[3];     // its base texel index
+};
+
+__device__ __forceinline__ AxisTaps axis_taps(float p)
+{
+    AxisTaps a;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float q = p + (float)(k - 1);          // pos + vec2(-1 | 0 | 1, ..)   util.rs:62-69
+        float b = __builtin_floorf(q);         // util.rs:47
+        a.t[k] = q - b;                        // :48
+        a.s[k] = 1.0f - a.t[k];                // :49
+        a.i[k] = f32_as_i32(b);                // :50
+    }
+    return a;
+}
+
+// u[r][c] = bilinear(g, p + (c - 1, r - 1)); returns false when the patch form does not apply
+__device__ __forceinline__ bool stencil_taps(const float* __restrict__ g, int32_t rows, int32_t cols,
+                                             float px, float py, float (&u)[3][3])
+{
+    AxisTaps ax = axis_taps(px), ay = axis_taps(py);
+    int64_t x0 = ax.i[0], y0 = ay.i[0];
+    if (ax.i[1] != x0 + 1 || ax.i[2] != x0 + 2 || ay.i[1] != y0 + 1 || ay.i[2] != y0 + 2)
+        return false;
+    float P[4][4];
+    if (x0 >= 0 && y0 >= 0 && x0 + 3 < cols && y0 + 3 < rows) {
+        const float* row = g + (size_t)y0 * (size_t)cols + (size_t)x0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) P[r][c] = row[c];
+            row += cols;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) P[r][c] = texel(g, rows, cols, x0 + c, y0 + r);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float y = 0.0f;                              // util.rs:52-56
+            y += ay.s[r] * ax.s[c] * P[r][c];
+            y += ay.s[r] * ax.t[c] * P[r][c + 1];
+            y += ay.t[r] * ax.s[c] * P[r + 1][c];
+            y += ay.t[r] * ax.t[c] * P[r + 1][c + 1];
+            u[r][c] = y;
+        }
+    return true;
+}
+
+// sobel_filter (util.rs:61-75) and, optionally, the centre sample (field.rs:242-245)
+__device__ __forceinline__ v2 sobel_fast(const float* __restrict__ g, int32_t rows, int32_t cols,
+                                         float px, float py, float* centre)
+{
+    float u[3][3];
+    if (!stencil_taps(g, rows, cols, px, py, u)) {
+        if (centre) *centre = bilinear(g, rows, cols, px, py);
+        return sobel(g, rows, cols, px, py);
+    }
+    if (centre) *centre = u[1][1];
+    return mk(u[0][0] + u[1][0] + u[1][0] + u[2][0] - u[0][2] - u[1][2] - u[1][2] - u[2][2],
+              u[0][0] + u[0][1] + u[0][1] + u[0][2] - u[2][0] - u[2][1] - u[2][1] - u[2][2]);
+}
+
 // field.rs:236,243,250,256: position / unit - 0.5 (the division is IEEE in both modes:
 // it decides which texels are read)
 __device__ __forceinline__ v2 field_coord(const FieldView& f, v2 pos)
@@ -184,14 +262,13 @@ __device__ __forceinline__ v2 field_coord(const FieldView& f, v2 pos)
 // ---- pair force (sfm.rs:131-153) -----------------------------------------------------
 #define PEDONI_COS_PHI (-0.17364817766693036f) /* sfm.rs:16 */
 
+// force on an agent from a neighbour, given difference = pos - pos_i with
+// |difference|^2 <= 4 already established (sfm.rs:137-153)
 template <int MODE>
-__device__ __forceinline__ void pair_force(v2 pos, v2 e, v2 pos_i, v2 vel_i, v2& acc,
-                                           const uint64_t* tab)
+__device__ __forceinline__ void pair_force_from_difference(v2 difference, v2 e, v2 vel_i, v2& acc,
+                                                           const uint64_t* tab)
 {
-    v2 difference = pos - pos_i;                         // :131
     float distance_squared = dot(difference, difference); // :132
-    if (distance_squared > 4.0f) return;                 // :133 (NaN falls through, as upstream)
-
     float distance = fsqrt<MODE>(distance_squared);      // :137
     v2 direction = difference * frcp<MODE>(distance);    // :138 normalize()
 
@@ -208,6 +285,16 @@ __device__ __forceinline__ void pair_force(v2 pos, v2 e, v2 pos_i, v2 vel_i, v2&
     if (dot(e, -force) < length<MODE>(force) * PEDONI_COS_PHI) // :149
         force = force * 0.5f;                            // :150
     acc = acc + force;                                   // :153
+}
+
+template <int MODE>
+__device__ __forceinline__ void pair_force(v2 pos, v2 e, v2 pos_i, v2 vel_i, v2& acc,
+                                           const uint64_t* tab)
+{
+    v2 difference = pos - pos_i;                         // :131
+    float distance_squared = dot(difference, difference); // :132
+    if (distance_squared > 4.0f) return;                 // :133 (NaN falls through, as upstream)
+    pair_force_from_difference<MODE>(difference, e, vel_i, acc, tab);
 }
 
 // util.rs:92-103

@@ -259,6 +259,7 @@ struct ForceArgs {
     GridView grid;
     int32_t band_lo, band_hi; // rows whose agents are integrated (others are ghosts)
     int32_t use_grid, use_distance_map;
+    int32_t ablate; // diagnostics only (PEDONI_ABLATE): 1 = no goal sampling, 2 = no obstacle term, 4 = no pairs
 };
 
 // goal force, sfm.rs:106-109
@@ -266,7 +267,7 @@ template <int MODE>
 __device__ __forceinline__ v2 goal_direction(const FieldView& f, v2 pos, uint32_t dest)
 {
     v2 q = field_coord(f, pos);
-    v2 g = sobel(f.potential_maps[dest], f.rows, f.cols, q.x, q.y);
+    v2 g = sobel_fast(f.potential_maps[dest], f.rows, f.cols, q.x, q.y, nullptr);
     return normalize<MODE>(g);
 }
 
@@ -275,8 +276,8 @@ template <int MODE>
 __device__ __forceinline__ v2 obstacle_force_map(const FieldView& f, v2 pos, const uint64_t* tab)
 {
     v2 q = field_coord(f, pos);
-    float distance = bilinear(f.distance_map, f.rows, f.cols, q.x, q.y);
-    v2 direction = -normalize<MODE>(sobel(f.distance_map, f.rows, f.cols, q.x, q.y));
+    float distance;
+    v2 direction = -normalize<MODE>(sobel_fast(f.distance_map, f.rows, f.cols, q.x, q.y, &distance));
     float k = (10.0f * 0.2f) * fexp<MODE>(fdiv<MODE>(-distance, 0.2f), tab);
     return direction * k;
 }
@@ -312,10 +313,12 @@ __device__ __forceinline__ void obstacle_force_segments(const PedoniObstacleDev*
     }
 }
 
-// v1 force kernel: one lane per agent, neighbours streamed from L1/L2 in the
-// reference's accumulation order (rows ascending, index ascending).
+// Simple force kernel: one lane per agent, neighbours streamed from L1/L2 in the
+// reference's accumulation order (rows ascending, index ascending).  Used for the
+// brute-force option path (use_neighbor_grid = false, sfm.rs:157-185) and as an
+// independent cross-check of force_kernel_queue in the GPU tests.
 template <int MODE>
-__global__ void force_kernel(ForceArgs a)
+__global__ void force_kernel_simple(ForceArgs a)
 {
     __shared__ uint64_t tab[32];
     if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
@@ -382,6 +385,187 @@ __global__ void force_kernel(ForceArgs a)
     float max_len = desired_speed * 1.3f;
     float length_sq = dot(vel, vel);
     if (length_sq > max_len * max_len) {                     // glam clamp_length_max
+        v2 q = vdiv<MODE>(vel, fsqrt<MODE>(length_sq));
+        vel = mk(max_len * q.x, max_len * q.y);
+    }
+    pos = pos + (vel + vel_prev) * 0.05f;
+    a.pos_out[id] = make_float2(pos.x, pos.y);
+    a.vel_out[id] = make_float2(vel.x, vel.y);
+}
+
+// ---- K_FORCE, wave-queue form (grid path) ----------------------------------------------
+// One lane owns one agent (sorted order, so a wave covers ~32 neighbouring cells), but
+// the expensive pair evaluation is decoupled from ownership:
+//   phase 1  every lane walks its own candidate list (3 contiguous index ranges, rows
+//            y-1..y+1) SLOTS candidates at a time and does only the cutoff test
+//            (|d|^2 > 4 -> skip, sfm.rs:133).  Survivors are compacted with
+//            ballot + mbcnt into a per-wave queue in LDS: {dx, dy, neighbour velocity} and
+//            the owner lane.
+//   phase 2  the queue is drained 64 entries at a time: every lane evaluates one pair
+//            force (3 sqrt, 6 div, 1 exp: the hot 95 %) with no divergence and
+//            overwrites its queue entry with the result.
+//   phase 3  each owner adds its results in candidate order -- rows ascending, index
+//            ascending, exactly the reference's `acc += force` sequence -- so the sum is
+//            bit-identical to the serial loop although pairs were evaluated in parallel.
+// The queue is private to a wave (LDS operations of one wave retire in order), so the
+// loop has no workgroup barrier.
+constexpr int FORCE_THREADS = 256;
+constexpr int FORCE_WAVES = FORCE_THREADS / 64;
+
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
+{
+    __shared__ uint64_t tab[32];
+    __shared__ float4 queue_all[FORCE_WAVES][SLOTS * 64];
+    __shared__ float2 e_all[FORCE_WAVES][64];
+    __shared__ unsigned char owner_all[FORCE_WAVES][SLOTS * 64];
+    if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float4* queue = queue_all[wave];
+    unsigned char* owner_of = owner_all[wave];
+    float2* e_lds = e_all[wave];
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = *a.live_count;
+    bool valid = id < n;
+
+    v2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), acc = mk(0.0f, 0.0f), e = mk(0.0f, 0.0f);
+    float2 vv = make_float2(0.0f, 0.0f);
+    float desired_speed = 0.0f;
+    uint32_t r0 = 0, r1 = 0, r2 = 0, n0 = 0, n1 = 0, n2 = 0;
+    bool ghost = false;
+    if (valid) {
+        float2 p = a.pos[id];
+        vv = a.vel[id];
+        pos = mk(p.x, p.y);
+        vel = mk(vv.x, vv.y);
+        desired_speed = a.v0[id];
+        uint32_t destination = a.dest[id];
+        int32_t ix = f32_as_i32(pos.x / a.grid.unit);            // sfm.rs:113
+        int32_t iy = f32_as_i32(pos.y / a.grid.unit);
+        ghost = iy < a.band_lo || iy >= a.band_hi;
+        if (!ghost) {
+            if (a.ablate & 1) e = mk(1.0f, 0.0f);
+            else e = goal_direction<MODE>(a.field, pos, destination); // :107-108
+            acc = acc + vdiv<MODE>(e * desired_speed - vel, 0.5f); // :109
+            int32_t y_start = max(iy - 1, 0), y_end = min(iy + 1, a.grid.rows - 1); // :117-118
+            int32_t x_start = max(ix - 1, 0), x_end = min(ix + 1, a.grid.cols - 1); // :119-120
+            // rows y_start..y_end in ascending order; a missing row contributes nothing
+            for (int32_t y = y_start, k = 0; y <= y_end; ++y, ++k) {
+                int64_t offset = (int64_t)y * a.grid.cols;
+                uint32_t i_start = a.cell_start[offset + x_start];
+                uint32_t i_end = a.cell_start[offset + x_end + 1];
+                if (k == 0) { r0 = i_start; n0 = i_end - i_start; }
+                else if (k == 1) { r1 = i_start; n1 = i_end - i_start; }
+                else { r2 = i_start; n2 = i_end - i_start; }
+            }
+        }
+    }
+    e_lds[lane] = make_float2(e.x, e.y);
+    const uint32_t cnt = (a.ablate & 4) ? 0u : n0 + n1 + n2;
+    uint32_t max_cnt = cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, off, 64));
+    max_cnt = __builtin_amdgcn_readfirstlane(max_cnt);
+
+    for (uint32_t base = 0; base < max_cnt; base += SLOTS) {
+        // ---- phase 1: cutoff test + compaction ---------------------------------------
+        // three unrolled sub-passes so that the SLOTS position loads, then the survivors'
+        // velocity loads, are all in flight together
+        uint32_t qlen = 0;       // wave-uniform
+        uint32_t passmask = 0;
+        uint32_t slot_of[SLOTS];
+        uint32_t idx[SLOTS];
+        float2 d[SLOTS], vi[SLOTS];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            uint32_t s = base + k;
+            idx[k] = s < n0 ? r0 + s : (s < n0 + n1 ? r1 + (s - n0) : r2 + (s - n0 - n1));
+            d[k] = make_float2(0.0f, 0.0f);
+            if (s < cnt) d[k] = a.pos[idx[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            bool pass = false;
+            if (base + k < cnt) {
+                float dx = pos.x - d[k].x;                        // :131
+                float dy = pos.y - d[k].y;
+                float d2 = (dx * dx) + (dy * dy);                 // :132
+                pass = !(d2 > 4.0f) && idx[k] != id;              // :130,133
+                d[k] = make_float2(dx, dy);
+            }
+            vi[k] = make_float2(0.0f, 0.0f);
+            if (pass) {
+                vi[k] = a.vel[idx[k]];                            // :140
+                passmask |= 1u << k;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            bool pass = (passmask >> k) & 1u;
+            unsigned long long mask = __ballot(pass);
+            uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                  __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            uint32_t slot = qlen + before;
+            slot_of[k] = slot;
+            if (pass) {
+                queue[slot] = make_float4(d[k].x, d[k].y, vi[k].x, vi[k].y);
+                owner_of[slot] = (unsigned char)lane;
+            }
+            qlen += (uint32_t)__popcll(mask);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase 2: one pair force per lane, no divergence, no global memory ----------
+        for (uint32_t q0 = 0; q0 < qlen; q0 += 64) {
+            uint32_t q = q0 + lane;
+            if (q < qlen) {
+                float4 en = queue[q];
+                float2 eo = e_lds[owner_of[q]];
+                v2 f = mk(0.0f, 0.0f);
+                pair_force_from_difference<MODE>(mk(en.x, en.y), mk(eo.x, eo.y), mk(en.z, en.w), f, tab);
+                reinterpret_cast<float2*>(&queue[q])[0] = make_float2(f.x, f.y);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase 3: ordered accumulation (sfm.rs:153) ---------------------------------
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            if (passmask & (1u << k)) {
+                float2 f = reinterpret_cast<const float2*>(&queue[slot_of[k]])[0];
+                acc = acc + mk(f.x, f.y);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (!valid) return;
+    if (ghost) {                                                  // ghost row: never integrated
+        if (a.pos_out) {                                          // NaN position = "not mine"; the
+            float qn = __builtin_nanf("");                        // next sort/despawn pass drops it
+            a.pos_out[id] = make_float2(qn, qn);
+            a.vel_out[id] = vv;
+        }
+        return;
+    }
+
+    if (a.ablate & 2) {}
+    else if (a.use_distance_map) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
+    else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
+
+    if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); return; }
+
+    // integrator, sfm.rs:245-254
+    v2 vel_prev = vel;
+    vel = vel + acc * 0.1f;
+    float max_len = desired_speed * 1.3f;
+    float length_sq = dot(vel, vel);
+    if (length_sq > max_len * max_len) {                          // glam clamp_length_max
         v2 q = vdiv<MODE>(vel, fsqrt<MODE>(length_sq));
         vel = mk(max_len * q.x, max_len * q.y);
     }

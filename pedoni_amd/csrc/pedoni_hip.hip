@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -117,6 +118,8 @@ struct PedoniModel {
     uint32_t n_upper = 0; // host upper bound of stored agents (live + stale + appended)
     uint32_t gap_end = 0; // [live, gap_end) are stale slots, [gap_end, n_upper) appended
     bool sorted = false;  // cell_start matches the current pos buffer
+    bool force_simple = false; // PEDONI_FORCE_SIMPLE=1: one-lane-per-agent force kernel
+    int ablate = 0;            // PEDONI_ABLATE bitmask: timing diagnostics only, results wrong
 
     // profiling
     bool profiling = false;
@@ -343,6 +346,7 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
     a.band_hi = m->band_hi;
     a.use_grid = m->opt.use_neighbor_grid;
     a.use_distance_map = m->opt.use_distance_map;
+    a.ablate = m->ablate;
     return a;
 }
 
@@ -354,10 +358,16 @@ int launch_force(PedoniModel* m, float2* acc_out)
     ForceArgs a = force_args(m, acc_out);
     Timed t(m, PEDONI_K_FORCE);
     if (t.rc) return t.rc;
-    if (m->opt.math_mode == PEDONI_MATH_FAST)
-        hipLaunchKernelGGL(force_kernel<1>, dim3(blocks_for(n, bs)), dim3(bs), 0, m->stream, a);
-    else
-        hipLaunchKernelGGL(force_kernel<0>, dim3(blocks_for(n, bs)), dim3(bs), 0, m->stream, a);
+    const bool fast = m->opt.math_mode == PEDONI_MATH_FAST;
+    if (m->opt.use_neighbor_grid && !m->force_simple) {
+        dim3 grid(blocks_for(n, FORCE_THREADS)), block(FORCE_THREADS);
+        if (fast) hipLaunchKernelGGL((force_kernel_queue<1, 8>), grid, block, 0, m->stream, a);
+        else hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, m->stream, a);
+    } else {
+        dim3 grid(blocks_for(n, bs)), block(bs);
+        if (fast) hipLaunchKernelGGL(force_kernel_simple<1>, grid, block, 0, m->stream, a);
+        else hipLaunchKernelGGL(force_kernel_simple<0>, grid, block, 0, m->stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return PEDONI_OK;
 }
@@ -480,6 +490,12 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
     m->size_x = size_x;
     m->size_y = size_y;
     m->rng.s = opt->seed;
+    {
+        const char* fs = std::getenv("PEDONI_FORCE_SIMPLE");
+        m->force_simple = fs && fs[0] == '1';
+        const char* ab = std::getenv("PEDONI_ABLATE");
+        m->ablate = ab ? std::atoi(ab) : 0;
+    }
     *out = nullptr;
 
     auto bail = [&](int rc) { pedoni_hip_destroy(m); return rc; };

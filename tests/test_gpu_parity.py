@@ -290,8 +290,10 @@ def test_trait_spawn_draws_speeds_like_the_host_mirror(hip, oracle):
 
 
 def test_fast_math_mode_within_1e5(hip, oracle):
-    """PEDONI_MATH_FAST: hardware rcp/rsq/exp; 1e-5 relative per step except agents whose
-    discrete decisions (cutoff, field-of-view halving, speed clamp) sit on a boundary."""
+    """PEDONI_MATH_FAST: hardware rcp/rsq/exp.  Bar: |dv| <= 1e-5 * max(|v|, 1e-3) and the
+    same for positions, per agent and per step from identical state -- except agents whose
+    discrete decisions (2 m cutoff, field-of-view halving, speed clamp) sit within an ulp
+    of a boundary, which flip with any 1-ulp change; those must stay below 2e-4 of agents."""
     sc = random_obstacle_scenario(200.0, 300)
     field = oracle_field(oracle, sc)
     n = 50_000
@@ -307,6 +309,32 @@ def test_fast_math_mode_within_1e5(hip, oracle):
     gp, gd, gv, g0 = gpu.download()
     wp, wd, wv, w0 = cpu.download()
     assert np.array_equal(gd, wd)
-    bad = ~(rel_close(gp, wp).all(axis=1) & rel_close(gv, wv).all(axis=1))
+
+    def vec_bad(g, w):
+        g, w = g.astype(np.float64), w.astype(np.float64)
+        err = np.linalg.norm(g - w, axis=1)
+        return ~(err <= 1e-5 * np.maximum(np.linalg.norm(w, axis=1), 1e-3)) & \
+            ~(np.isnan(g).any(axis=1) & np.isnan(w).any(axis=1))
+
+    bad = vec_bad(gp, wp) | vec_bad(gv, wv)
     assert bad.mean() < 2e-4, f"{bad.sum()} of {n} agents outside 1e-5 in fast mode"
     gpu.close()
+
+
+def test_queue_and_simple_force_kernels_agree(hip, oracle, monkeypatch):
+    """The wave-queue force kernel and the one-lane-per-agent kernel are independent
+    implementations of sfm.rs:93-241; both must reproduce the oracle bit for bit."""
+    sc = random_obstacle_scenario(120.0, 100)
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 30_000, 4, seed=33)
+    cpu = oracle.OracleModel(sc.field.size)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    want = cpu.calc_accelerations(field)
+    for simple in ("0", "1"):
+        monkeypatch.setenv("PEDONI_FORCE_SIMPLE", simple)
+        gpu = _make_hip(hip, sc, field)
+        gpu.append(pos, dest, v0, vel)
+        gpu.sort_despawn()
+        got = gpu.calc_accelerations(len(want))
+        assert bit_equal(got, want).all(), f"PEDONI_FORCE_SIMPLE={simple}"
+        gpu.close()
