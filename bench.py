@@ -185,16 +185,27 @@ def main() -> None:
     barrier()
     n_before = model.owned_count() if G > 1 else model.get_pedestrian_count()
     if not args.no_profile:
-        model.profile(True)
+        # one hipEvent pair per step around the dominant kernel only (a pair around every
+        # kernel costs ~40 us/step; the full breakdown is taken after the timed region)
+        model.profile(True, kernels=[abi.K_FORCE])
         model.kernel_times(reset=True)
     barrier()
     t0 = time.perf_counter()
     step_fn(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    ktimes = model.kernel_times() if not args.no_profile else {}
+    ktimes = model.kernel_times(reset=True) if not args.no_profile else {}
     model.profile(False)
     n_after = model.owned_count() if G > 1 else model.get_pedestrian_count()
+    breakdown = {}
+    if not args.no_profile:
+        model.profile(True)
+        step_fn(min(args.steps, 20))
+        barrier()
+        bt = model.kernel_times(reset=True)
+        model.profile(False)
+        breakdown = {k: v["total_ms"] / max(v["launches"], 1) * (v["launches"] / min(args.steps, 20))
+                     for k, v in bt.items() if v["launches"]}
 
     agents_local = 0.5 * (n_before + n_after)       # despawns during the run are negligible
     if dist is not None:
@@ -230,8 +241,7 @@ def main() -> None:
                 "kernel": "force_integrate", "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": BYTES_FORCE * agents_local,
             }
-            out["kernel_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in ktimes.items()
-                                         if v["launches"]}
+            out["kernel_ms_per_step"] = breakdown  # separate pass, every kernel event-timed
         else:
             out["roofline"] = None
         if G == 1 and not args.no_cpu_baseline:

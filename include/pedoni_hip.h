@@ -78,10 +78,10 @@ typedef struct {
     uint64_t launches[PEDONI_N_KERNELS];
 } PedoniKernelTimes;
 /* indices into PedoniKernelTimes */
-#define PEDONI_K_BIN 0       /* cell key + despawn test + per-cell count   */
+#define PEDONI_K_BIN 0       /* cell key + despawn test, per-cell count     */
 #define PEDONI_K_SCAN 1      /* exclusive scan -> neighbor_grid_indices     */
-#define PEDONI_K_SLOT 2      /* write agent index into its cell's slot range */
-#define PEDONI_K_REORDER 3   /* stable in-cell rank + SoA scatter            */
+#define PEDONI_K_SLOT 2      /* stable gather of each cell's agents (or slot) */
+#define PEDONI_K_REORDER 3   /* general form: in-cell rank + SoA scatter     */
 #define PEDONI_K_FORCE 4     /* goal + pair + obstacle force + integrator    */
 #define PEDONI_K_HALO_PACK 5
 #define PEDONI_K_HALO_UNPACK 6
@@ -145,7 +145,9 @@ int pedoni_hip_calc_accelerations(PedoniModel* m, float* acc_xy, uint32_t cap);
 int pedoni_hip_set_stream(PedoniModel* m, void* hip_stream); /* NULL -> library stream */
 int pedoni_hip_get_stream(PedoniModel* m, void** hip_stream);
 int pedoni_hip_synchronize(PedoniModel* m);
-int pedoni_hip_profile(PedoniModel* m, int32_t enable);      /* hipEvent pair per kernel */
+/* bit k of `kernel_mask` = time launches of PEDONI_K_<k> with a hipEvent pair (-1 = all,
+ * 0 = off).  An event pair costs a few microseconds per launch on the stream. */
+int pedoni_hip_profile(PedoniModel* m, int32_t kernel_mask);
 int pedoni_hip_kernel_times(PedoniModel* m, PedoniKernelTimes* out, int32_t reset);
 const char* pedoni_hip_kernel_name(int32_t k);
 

@@ -18,6 +18,7 @@ _ROOT = Path(__file__).resolve().parent
 _LIB: Optional[C.CDLL] = None
 
 N_KERNELS = 8
+K_BIN, K_SCAN, K_SLOT, K_REORDER, K_FORCE, K_HALO_PACK, K_HALO_UNPACK, K_OTHER = range(8)
 MATH_EXACT = 0
 MATH_FAST = 1
 HALO_HEADER_WORDS = 4
@@ -300,8 +301,13 @@ class HipModel:
     def synchronize(self) -> None:
         _check(self._lib, self._lib.pedoni_hip_synchronize(self._h))
 
-    def profile(self, enable: bool) -> None:
-        _check(self._lib, self._lib.pedoni_hip_profile(self._h, C.c_int32(int(enable))))
+    def profile(self, enable, kernels: Optional[Sequence[int]] = None) -> None:
+        """Time kernel launches with hipEvent pairs: all kernels, or only the PEDONI_K_*
+        indices in `kernels` (each pair costs a few microseconds on the stream)."""
+        mask = 0
+        if enable:
+            mask = 0xFF if kernels is None else sum(1 << k for k in kernels)
+        _check(self._lib, self._lib.pedoni_hip_profile(self._h, C.c_int32(mask)))
 
     def kernel_times(self, reset: bool = False) -> dict:
         t = _KernelTimes()

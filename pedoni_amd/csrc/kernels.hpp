@@ -43,36 +43,116 @@ __device__ __forceinline__ bool survives(const FieldView& f, v2 pos, uint32_t de
     return bilinear(f.potential_maps[dest], f.rows, f.cols, q.x, q.y) > 0.25f;
 }
 
-// ---- K_BIN ---------------------------------------------------------------------------
+// ---- the sort/despawn pass (sfm.rs:58-77) on the device -----------------------------------
+// The reference bins every agent, then walks the cells row-major and each cell's list in
+// insertion order: a STABLE sort by cell id, fused with the despawn test.  Two device forms
+// produce exactly that order:
+//
+//  gather form (steady state).  Agents are still in last tick's sorted order and move
+//    far less than one cell per tick, so the members of new cell c all sit in the 3 x 3
+//    OLD cells around c -- three contiguous index ranges.  One thread per cell counts /
+//    copies the agents of those ranges whose new key is c, in index order: no atomics, no
+//    ranks, and the scan of the ranges is itself the reference's insertion order.
+//  general form.  Any agent that is new (appended) or moved farther than one cell raises
+//    a device flag in K_KEY; then the same launches take their other branch: per-cell
+//    counts by integer atomics (exact whatever the arrival order), a provisional slot per
+//    agent, and K_REORDER restores insertion order by counting the cell-mates with a
+//    smaller previous index.
+// The branch is chosen on the device, per tick, with no host round trip.
+
+struct SortFlags {
+    uint32_t far[2]; // far[tick & 1] != 0 -> general form this tick
+};
+
+__device__ __forceinline__ uint32_t pack_cell(uint32_t cx, uint32_t cy) { return (cy << 16) | cx; }
+
+// ---- K_KEY (PEDONI_K_BIN) ----------------------------------------------------------------
 // One thread per stored agent.  Slots [live, gap_end) hold agents despawned by earlier
 // ticks (the host only knows an upper bound of the live count) and are skipped.
-// Integer atomics make cell_count exact whatever the arrival order; the arrival rank is
-// only a provisional slot, K_REORDER restores the reference's order.
-__global__ void bin_kernel(const float2* __restrict__ pos, const uint32_t* __restrict__ dest,
+__global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __restrict__ dest,
                            uint32_t n_total, const uint32_t* __restrict__ live_count,
                            uint32_t gap_end, FieldView field, GridView grid, int32_t band_lo,
-                           int32_t band_hi, uint32_t* __restrict__ cell_count,
-                           uint32_t* __restrict__ key, uint32_t* __restrict__ rank)
+                           int32_t band_hi, const uint32_t* __restrict__ skey_old,
+                           int32_t force_general, uint32_t parity, SortFlags* __restrict__ flags,
+                           uint32_t* __restrict__ key)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        flags->far[parity ^ 1u] = 0;              // nobody reads the other tick's flag now
+        if (force_general) atomicOr(&flags->far[parity], 1u);
+    }
     if (i >= n_total) return;
     uint32_t live = *live_count;
-    uint32_t k = DEAD, r = 0;
+    uint32_t k = DEAD;
     if (i < live || i >= gap_end) {
         float2 p = pos[i];
         v2 pp = mk(p.x, p.y);
         int64_t c = cell_of(grid, pp);
         if (c >= 0 && survives(field, pp, dest[i])) {
-            int32_t row = (int32_t)(c / grid.cols);
+            int32_t cy = (int32_t)(c / grid.cols), cx = (int32_t)(c - (int64_t)cy * grid.cols);
             // sharded runs keep only the band's rows plus one ghost row either side
-            if (row >= band_lo - 1 && row <= band_hi) {
+            if (cy >= band_lo - 1 && cy <= band_hi) {
                 k = (uint32_t)c;
-                r = atomicAdd(&cell_count[c], 1u);
+                bool far = i >= gap_end;           // appended since the last pass
+                if (!far && !force_general) {
+                    uint32_t old = skey_old[i];
+                    int32_t ox = (int32_t)(old & 0xffffu), oy = (int32_t)(old >> 16);
+                    far = abs(cx - ox) > 1 || abs(cy - oy) > 1;
+                }
+                if (far) atomicOr(&flags->far[parity], 1u);
             }
         }
     }
     key[i] = k;
-    rank[i] = r;
+}
+
+// the three old index ranges that can hold members of new cell (cx, cy)
+struct CellRanges { uint32_t lo[3], hi[3]; };
+__device__ __forceinline__ CellRanges old_ranges(const uint32_t* __restrict__ cs_old, const GridView& g,
+                                                 int32_t cx, int32_t cy)
+{
+    CellRanges r;
+    int32_t x0 = max(cx - 1, 0), x1 = min(cx + 1, g.cols - 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int32_t y = cy - 1 + k;
+        if (y < 0 || y >= g.rows) { r.lo[k] = r.hi[k] = 0; continue; }
+        int64_t off = (int64_t)y * g.cols;
+        r.lo[k] = cs_old[off + x0];
+        r.hi[k] = cs_old[off + x1 + 1];
+    }
+    return r;
+}
+
+// ---- K_COUNT (timed with PEDONI_K_BIN) ------------------------------------------------------
+// gather form: agent j scans the three old ranges of its NEW cell once, in index order;
+// rank = members before j = its place in the reference's per-cell list, and the last
+// member publishes the cell's count (cell_count was zeroed by the previous scan).
+__global__ void count_kernel(const uint32_t* __restrict__ key, uint32_t n_total, GridView grid,
+                             const uint32_t* __restrict__ cs_old,
+                             const SortFlags* __restrict__ flags, uint32_t parity,
+                             uint32_t* __restrict__ cell_count, uint32_t* __restrict__ rank)
+{
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_total) return;
+    uint32_t c = key[j];
+    if (c == DEAD) return;
+    if (flags->far[parity] == 0) {
+        int32_t cy = (int32_t)(c / (uint32_t)grid.cols), cx = (int32_t)(c - (uint32_t)cy * (uint32_t)grid.cols);
+        CellRanges r = old_ranges(cs_old, grid, cx, cy);
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            for (uint32_t i = r.lo[k]; i < r.hi[k]; ++i) {
+                uint32_t hit = key[i] == c ? 1u : 0u;
+                total += hit;
+                before += (i < j) ? hit : 0u;
+            }
+        rank[j] = before;
+        if (before + 1 == total) cell_count[c] = total;
+    } else {
+        rank[j] = atomicAdd(&cell_count[c], 1u);   // general form: provisional arrival rank
+    }
 }
 
 // no-grid variant (sfm.rs:78-88): survivors keep their order; key = 1/0 flag to be scanned
@@ -188,41 +268,57 @@ scan_apply_kernel(uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restr
     }
 }
 
-// ---- K_SLOT --------------------------------------------------------------------------
-__global__ void slot_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ rank,
-                            uint32_t n_total, const uint32_t* __restrict__ cell_start,
-                            uint32_t* __restrict__ slots)
+// ---- K_WRITE (PEDONI_K_SLOT) ----------------------------------------------------------------
+struct SoA {
+    const float2* pos_in; const float2* vel_in; const float* v0_in; const uint32_t* dest_in;
+    float2* pos_out; float2* vel_out; float* v0_out; uint32_t* dest_out;
+    uint32_t* skey_out;
+};
+
+__device__ __forceinline__ void move_agent(const SoA& a, uint32_t from, uint32_t to, uint32_t packed)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
-    uint32_t k = key[i];
-    if (k != DEAD) slots[cell_start[k] + rank[i]] = i;
+    a.pos_out[to] = a.pos_in[from];
+    a.vel_out[to] = a.vel_in[from];
+    a.v0_out[to] = a.v0_in[from];
+    a.dest_out[to] = a.dest_in[from];
+    a.skey_out[to] = packed;
 }
 
-// ---- K_REORDER -----------------------------------------------------------------------
-// sfm.rs:66-75 walks the cells row-major and each cell's list in insertion order, i.e. a
-// STABLE sort by cell id.  An agent's place inside its cell is the number of cell-mates
-// with a smaller previous index; the slot list gives those indices in arbitrary order.
-__global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t n_total,
-                               const uint32_t* __restrict__ cell_start,
-                               const uint32_t* __restrict__ slots,
-                               const float2* __restrict__ pos_in, const float2* __restrict__ vel_in,
-                               const float* __restrict__ v0_in, const uint32_t* __restrict__ dest_in,
-                               float2* __restrict__ pos_out, float2* __restrict__ vel_out,
-                               float* __restrict__ v0_out, uint32_t* __restrict__ dest_out)
+__global__ void write_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ rank,
+                             uint32_t n_total, GridView grid, const uint32_t* __restrict__ cs_new,
+                             const SortFlags* __restrict__ flags, uint32_t parity, SoA a,
+                             uint32_t* __restrict__ slots)
 {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_total) return;
+    uint32_t c = key[j];
+    if (c == DEAD) return;
+    uint32_t p = cs_new[c] + rank[j];
+    if (flags->far[parity] == 0) {                 // gather form: rank is final
+        uint32_t cy = c / (uint32_t)grid.cols, cx = c - cy * (uint32_t)grid.cols;
+        move_agent(a, j, p, pack_cell(cx, cy));
+    } else {                                       // general form: provisional slot
+        slots[p] = j;
+    }
+}
+
+// ---- K_REORDER (general form only) --------------------------------------------------------
+// sfm.rs:66-75: an agent's place inside its cell is the number of cell-mates with a smaller
+// previous index; the slot list gives those indices in arbitrary (atomic arrival) order.
+__global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t n_total, GridView grid,
+                               const uint32_t* __restrict__ cs_new, const uint32_t* __restrict__ slots,
+                               const SortFlags* __restrict__ flags, uint32_t parity, SoA a)
+{
+    if (flags->far[parity] == 0) return;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
     uint32_t k = key[i];
     if (k == DEAD) return;
-    uint32_t base = cell_start[k], end = cell_start[k + 1];
+    uint32_t base = cs_new[k], end = cs_new[k + 1];
     uint32_t before = 0;
     for (uint32_t j = base; j < end; ++j) before += slots[j] < i ? 1u : 0u;
-    uint32_t p = base + before;
-    pos_out[p] = pos_in[i];
-    vel_out[p] = vel_in[i];
-    v0_out[p] = v0_in[i];
-    dest_out[p] = dest_in[i];
+    uint32_t cy = k / (uint32_t)grid.cols, cx = k - cy * (uint32_t)grid.cols;
+    move_agent(a, i, base + before, pack_cell(cx, cy));
 }
 
 // no-grid compaction: survivor i goes to its exclusive flag prefix

@@ -106,7 +106,13 @@ struct PedoniModel {
     uint32_t* d_rank = nullptr;
     uint32_t* d_slots = nullptr;
     uint32_t* d_scan_in = nullptr;  // cell_count (grid) or flags (no grid)
-    uint32_t* d_scan_out = nullptr; // cell_start (grid) or prefix (no grid)
+    uint32_t* d_cs[2] = {nullptr, nullptr}; // cell_start ping-pong (grid) / prefix (no grid, [0])
+    int cs = 0;                     // d_cs[cs] = neighbor_grid_indices of the current order
+    uint32_t* d_skey[2] = {nullptr, nullptr}; // packed (cy << 16 | cx) cell of each sorted agent
+    int sk = 0;
+    SortFlags* d_flags = nullptr;
+    uint32_t tick_parity = 0;
+    bool have_old = false;          // d_cs[cs] / d_skey[sk] describe the stored order
     uint32_t scan_cap = 0;
     uint32_t* d_block_sums = nullptr;
     uint32_t block_sums_cap = 0;
@@ -120,9 +126,10 @@ struct PedoniModel {
     bool sorted = false;  // cell_start matches the current pos buffer
     bool force_simple = false; // PEDONI_FORCE_SIMPLE=1: one-lane-per-agent force kernel
     int ablate = 0;            // PEDONI_ABLATE bitmask: timing diagnostics only, results wrong
+    bool sort_general = false; // PEDONI_SORT_GENERAL=1: always take the atomic (general) sort form
 
     // profiling
-    bool profiling = false;
+    uint32_t profile_mask = 0;
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
     PedoniKernelTimes times{};
@@ -158,7 +165,7 @@ struct Timed {
     int rc = PEDONI_OK;
     Timed(PedoniModel* m_, int kernel) : m(m_)
     {
-        if (!m->profiling) return;
+        if (!((m->profile_mask >> kernel) & 1u)) return;
         if (m->ev_used == m->ev_pool.size()) {
             if (m->ev_pool.size() >= 8192) {
                 rc = drain_events(m);
@@ -222,25 +229,29 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
         m->d_pos[k] = npos[k]; m->d_vel[k] = nvel[k]; m->d_v0[k] = nv0[k]; m->d_dest[k] = ndest[k];
     }
     hipFree(m->d_key); hipFree(m->d_rank); hipFree(m->d_slots);
+    hipFree(m->d_skey[0]); hipFree(m->d_skey[1]);
     TRY(dev_alloc(&m->d_key, ncap));
     TRY(dev_alloc(&m->d_rank, ncap));
     TRY(dev_alloc(&m->d_slots, ncap));
+    TRY(dev_alloc(&m->d_skey[0], ncap));
+    TRY(dev_alloc(&m->d_skey[1], ncap));
+    m->have_old = false; // the per-agent old-cell array did not survive the reallocation
     m->cap = ncap;
 
     if (!m->opt.use_neighbor_grid) {
         // the scan runs over per-agent flags
-        hipFree(m->d_scan_in); hipFree(m->d_scan_out); hipFree(m->d_block_sums);
+        hipFree(m->d_scan_in); hipFree(m->d_cs[0]); hipFree(m->d_block_sums);
         m->scan_cap = ncap + 1;
         TRY(dev_alloc(&m->d_scan_in, m->scan_cap));
-        TRY(dev_alloc(&m->d_scan_out, m->scan_cap));
+        TRY(dev_alloc(&m->d_cs[0], m->scan_cap));
         m->block_sums_cap = (m->scan_cap + SCAN_TILE - 1) / SCAN_TILE + 1;
         TRY(dev_alloc(&m->d_block_sums, m->block_sums_cap));
     }
     return PEDONI_OK;
 }
 
-// exclusive scan of d_scan_in[0..n) -> d_scan_out[0..n), total -> d_scan_out[n] and d_live
-int run_scan(PedoniModel* m, uint32_t n, int zero_input)
+// exclusive scan of d_scan_in[0..n) -> out[0..n), total -> out[n] and d_live
+int run_scan(PedoniModel* m, uint32_t n, int zero_input, uint32_t* out)
 {
     Timed t(m, PEDONI_K_SCAN);
     if (t.rc) return t.rc;
@@ -249,9 +260,9 @@ int run_scan(PedoniModel* m, uint32_t n, int zero_input)
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream,
                        m->d_scan_in, n, m->d_block_sums);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, m->stream, m->d_block_sums,
-                       n_blocks, m->d_scan_out + n, m->d_live);
+                       n_blocks, out + n, m->d_live);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream,
-                       m->d_scan_in, n, m->d_block_sums, m->d_scan_out, zero_input);
+                       m->d_scan_in, n, m->d_block_sums, out, zero_input);
     HIP_TRY(hipGetLastError());
     return PEDONI_OK;
 }
@@ -268,35 +279,50 @@ int sort_despawn(PedoniModel* m)
         // nothing stored: live count 0, cell_start all zero
         HIP_TRY(hipMemsetAsync(m->d_live, 0, sizeof(uint32_t), m->stream));
         if (m->opt.use_neighbor_grid)
-            HIP_TRY(hipMemsetAsync(m->d_scan_out, 0, (size_t)(m->n_cells + 1) * sizeof(uint32_t),
+            HIP_TRY(hipMemsetAsync(m->d_cs[m->cs], 0, (size_t)(m->n_cells + 1) * sizeof(uint32_t),
                                    m->stream));
+        m->have_old = false;
         m->sorted = true;
         return PEDONI_OK;
     }
     if (m->opt.use_neighbor_grid) {
+        const int cs_old = m->cs, cs_new = 1 - m->cs, sk_old = m->sk, sk_new = 1 - m->sk;
+        const uint32_t parity = m->tick_parity & 1u;
+        // the gather form needs last tick's order and 16-bit cell coordinates
+        const bool packable = m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
+        const int force_general = (!m->have_old || !packable || m->sort_general) ? 1 : 0;
+        SoA soa{m->d_pos[src], m->d_vel[src], m->d_v0[vsrc], m->d_dest[vsrc],
+                m->d_pos[dst], m->d_vel[dst], m->d_v0[vdst], m->d_dest[vdst], m->d_skey[sk_new]};
         {
             Timed t(m, PEDONI_K_BIN);
             if (t.rc) return t.rc;
-            hipLaunchKernelGGL(bin_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0, m->stream,
+            hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0, m->stream,
                                m->d_pos[src], m->d_dest[vsrc], n_total, m->d_live, m->gap_end,
-                               m->field, m->grid, m->band_lo, m->band_hi, m->d_scan_in, m->d_key,
-                               m->d_rank);
+                               m->field, m->grid, m->band_lo, m->band_hi, m->d_skey[sk_old],
+                               force_general, parity, m->d_flags, m->d_key);
+            hipLaunchKernelGGL(count_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0,
+                               m->stream, m->d_key, n_total, m->grid, m->d_cs[cs_old],
+                               m->d_flags, parity, m->d_scan_in, m->d_rank);
         }
-        TRY(run_scan(m, m->n_cells, /*zero_input=*/1));
+        TRY(run_scan(m, m->n_cells, /*zero_input=*/1, m->d_cs[cs_new]));
         {
             Timed t(m, PEDONI_K_SLOT);
             if (t.rc) return t.rc;
-            hipLaunchKernelGGL(slot_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0, m->stream,
-                               m->d_key, m->d_rank, n_total, m->d_scan_out, m->d_slots);
+            hipLaunchKernelGGL(write_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0,
+                               m->stream, m->d_key, m->d_rank, n_total, m->grid,
+                               m->d_cs[cs_new], m->d_flags, parity, soa, m->d_slots);
         }
         {
             Timed t(m, PEDONI_K_REORDER);
             if (t.rc) return t.rc;
             hipLaunchKernelGGL(reorder_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0,
-                               m->stream, m->d_key, n_total, m->d_scan_out, m->d_slots,
-                               m->d_pos[src], m->d_vel[src], m->d_v0[vsrc], m->d_dest[vsrc],
-                               m->d_pos[dst], m->d_vel[dst], m->d_v0[vdst], m->d_dest[vdst]);
+                               m->stream, m->d_key, n_total, m->grid, m->d_cs[cs_new], m->d_slots,
+                               m->d_flags, parity, soa);
         }
+        m->cs = cs_new;
+        m->sk = sk_new;
+        m->tick_parity += 1;
+        m->have_old = true;
     } else {
         {
             Timed t(m, PEDONI_K_BIN);
@@ -308,12 +334,12 @@ int sort_despawn(PedoniModel* m)
         // d_key keeps the flags: the scan may not zero what compact still reads
         HIP_TRY(hipMemcpyAsync(m->d_key, m->d_scan_in, (size_t)n_total * sizeof(uint32_t),
                                hipMemcpyDeviceToDevice, m->stream));
-        TRY(run_scan(m, n_total, /*zero_input=*/0));
+        TRY(run_scan(m, n_total, /*zero_input=*/0, m->d_cs[0]));
         {
             Timed t(m, PEDONI_K_REORDER);
             if (t.rc) return t.rc;
             hipLaunchKernelGGL(compact_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0,
-                               m->stream, m->d_key, m->d_scan_out, n_total, m->d_pos[src],
+                               m->stream, m->d_key, m->d_cs[0], n_total, m->d_pos[src],
                                m->d_vel[src], m->d_v0[vsrc], m->d_dest[vsrc], m->d_pos[dst],
                                m->d_vel[dst], m->d_v0[vdst], m->d_dest[vdst]);
         }
@@ -337,7 +363,7 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
     a.vel_out = acc_out ? nullptr : m->d_vel[1 - m->pv];
     a.acc_out = acc_out;
     a.live_count = m->d_live;
-    a.cell_start = m->d_scan_out;
+    a.cell_start = m->d_cs[m->cs];
     a.obstacles = m->d_obstacles;
     a.n_obstacles = m->n_obstacles;
     a.field = m->field;
@@ -495,6 +521,8 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
         m->force_simple = fs && fs[0] == '1';
         const char* ab = std::getenv("PEDONI_ABLATE");
         m->ablate = ab ? std::atoi(ab) : 0;
+        const char* sg = std::getenv("PEDONI_SORT_GENERAL");
+        m->sort_general = sg && sg[0] == '1';
     }
     *out = nullptr;
 
@@ -544,9 +572,11 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
         m->n_cells = (uint32_t)m->grid.rows * (uint32_t)m->grid.cols;
         m->scan_cap = m->n_cells + 1;
         C_TRY(dev_alloc(&m->d_scan_in, m->scan_cap));
-        C_TRY(dev_alloc(&m->d_scan_out, m->scan_cap));
         C_HIP(hipMemset(m->d_scan_in, 0, (size_t)m->scan_cap * sizeof(uint32_t)));
-        C_HIP(hipMemset(m->d_scan_out, 0, (size_t)m->scan_cap * sizeof(uint32_t)));
+        for (int k = 0; k < 2; ++k) {
+            C_TRY(dev_alloc(&m->d_cs[k], m->scan_cap));
+            C_HIP(hipMemset(m->d_cs[k], 0, (size_t)m->scan_cap * sizeof(uint32_t)));
+        }
         m->block_sums_cap = (m->scan_cap + SCAN_TILE - 1) / SCAN_TILE + 1;
         C_TRY(dev_alloc(&m->d_block_sums, m->block_sums_cap));
     }
@@ -555,6 +585,8 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
 
     C_TRY(dev_alloc(&m->d_live, 4));
     C_HIP(hipMemset(m->d_live, 0, 4 * sizeof(uint32_t)));
+    C_TRY(dev_alloc(&m->d_flags, 1));
+    C_HIP(hipMemset(m->d_flags, 0, sizeof(SortFlags)));
     C_HIP(hipHostMalloc((void**)&m->h_pinned, 16 * sizeof(uint32_t), hipHostMallocDefault));
     C_TRY(ensure_capacity(m, std::max<uint32_t>(opt->initial_capacity, 1024)));
     C_HIP(hipDeviceSynchronize());
@@ -574,7 +606,8 @@ void pedoni_hip_destroy(PedoniModel* m)
         hipFree(m->d_pos[k]); hipFree(m->d_vel[k]); hipFree(m->d_v0[k]); hipFree(m->d_dest[k]);
     }
     hipFree(m->d_key); hipFree(m->d_rank); hipFree(m->d_slots);
-    hipFree(m->d_scan_in); hipFree(m->d_scan_out); hipFree(m->d_block_sums);
+    hipFree(m->d_scan_in); hipFree(m->d_cs[0]); hipFree(m->d_cs[1]); hipFree(m->d_block_sums);
+    hipFree(m->d_skey[0]); hipFree(m->d_skey[1]); hipFree(m->d_flags);
     hipFree(m->d_live); hipFree(m->d_acc);
     if (m->h_pinned) hipHostFree(m->h_pinned);
     hipFree(m->d_distance_map);
@@ -729,9 +762,10 @@ int pedoni_hip_clear(PedoniModel* m)
     TRY(bind(m));
     HIP_TRY(hipMemsetAsync(m->d_live, 0, sizeof(uint32_t), m->stream));
     if (m->opt.use_neighbor_grid)
-        HIP_TRY(hipMemsetAsync(m->d_scan_out, 0, (size_t)(m->n_cells + 1) * sizeof(uint32_t),
+        HIP_TRY(hipMemsetAsync(m->d_cs[m->cs], 0, (size_t)(m->n_cells + 1) * sizeof(uint32_t),
                                m->stream));
     m->n_upper = m->gap_end = 0;
+    m->have_old = false;
     m->sorted = false;
     return PEDONI_OK;
 }
@@ -743,7 +777,7 @@ int pedoni_hip_neighbor_grid_indices(PedoniModel* m, uint32_t* out, uint32_t cap
     uint32_t n = m->n_cells + 1;
     if (len) *len = n;
     if (out && cap) {
-        HIP_TRY(hipMemcpyAsync(out, m->d_scan_out, (size_t)std::min(n, cap) * sizeof(uint32_t),
+        HIP_TRY(hipMemcpyAsync(out, m->d_cs[m->cs], (size_t)std::min(n, cap) * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
     }
@@ -805,7 +839,7 @@ int pedoni_hip_profile(PedoniModel* m, int32_t enable)
 {
     TRY(bind(m));
     TRY(drain_events(m));
-    m->profiling = enable != 0;
+    m->profile_mask = (uint32_t)enable & ((1u << PEDONI_N_KERNELS) - 1u);
     return PEDONI_OK;
 }
 

@@ -229,6 +229,64 @@ def test_many_agents_in_one_cell_keep_insertion_order(hip, oracle):
     gpu.close()
 
 
+# ---- the two device forms of the sort/despawn pass -----------------------------------------
+def test_gather_and_general_sort_forms_agree(hip, oracle, monkeypatch):
+    """Steady-state gather form vs the atomic general form: same cell index, same order."""
+    sc = random_obstacle_scenario(150.0, 100)
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 40_000, 4, seed=44)
+    states = {}
+    for general in ("0", "1"):
+        monkeypatch.setenv("PEDONI_SORT_GENERAL", general)
+        gpu = _make_hip(hip, sc, field)
+        gpu.append(pos, dest, v0, vel)
+        gpu.tick_n(6)
+        gpu.sort_despawn()
+        states[general] = (gpu.download(), gpu.neighbor_grid_indices())
+        gpu.close()
+    (a, ia), (b, ib) = states["0"], states["1"]
+    assert np.array_equal(ia, ib)
+    for x, y in zip(a, b):
+        assert bit_equal(x.astype(np.float32), y.astype(np.float32)).all()
+    cpu = oracle.OracleModel(sc.field.size)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    for _ in range(6):
+        cpu.update_states(field)
+        cpu.spawn_pedestrians(field)
+    _assert_state_equal(a, cpu.download(), "after 6 ticks")
+
+
+def test_far_movers_and_spawns_switch_to_general_form(hip, oracle):
+    """Agents that jump several cells in one tick (huge injected speed) and agents spawned
+    mid-run must still land in the reference's order: the device flag selects the general
+    form for exactly those ticks."""
+    sc = box_scenario(80.0)
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 6000, 2, seed=45)
+    v0[:50] = 60.0                      # 1.3 * 60 m/s * 0.1 s = 7.8 m per tick: > 5 cells
+    vel[:50] = [55.0, 10.0]
+    cpu = oracle.OracleModel(sc.field.size, seed=5)
+    gpu = _make_hip(hip, sc, field, seed=5)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    rng = np.random.default_rng(46)
+    for step in range(8):
+        cpu.update_states(field)
+        gpu.update_states()
+        if step in (2, 3, 6):           # Simulator::tick with periodic spawners (lib.rs:70-85)
+            new = rng.uniform(20, 60, (37, 2)).astype(np.float32)
+            nd = rng.integers(0, 2, 37).astype(np.uint32)
+            cpu.spawn_pedestrians(field, new, nd)
+            gpu.spawn_pedestrians(new, nd)
+        else:
+            cpu.spawn_pedestrians(field)
+            gpu.spawn_pedestrians()
+        assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices()), step
+        _assert_state_equal(gpu.download(), cpu.download(), f"step {step} sorted")
+    gpu.close()
+
+
 # ---- option paths ------------------------------------------------------------------------
 def test_no_neighbor_grid_bruteforce_path(hip, oracle):
     """use_neighbor_grid = false: filter-only despawn (sfm.rs:78-88), O(N^2) pairs (:157-185)."""
