@@ -142,7 +142,9 @@ int pedoni_hip_neighbor_grid_shape(PedoniModel* m, uint32_t* rows, uint32_t* col
 int pedoni_hip_calc_accelerations(PedoniModel* m, float* acc_xy, uint32_t cap);
 
 /* [ext] stream / timing */
-int pedoni_hip_set_stream(PedoniModel* m, void* hip_stream); /* NULL -> library stream */
+/* All launches and copies of the model go to `hip_stream` (a hipStream_t; NULL is HIP's
+ * default stream) or, with use_library_stream != 0, back to the model's own stream. */
+int pedoni_hip_set_stream(PedoniModel* m, void* hip_stream, int32_t use_library_stream);
 int pedoni_hip_get_stream(PedoniModel* m, void** hip_stream);
 int pedoni_hip_synchronize(PedoniModel* m);
 /* bit k of `kernel_mask` = time launches of PEDONI_K_<k> with a hipEvent pair (-1 = all,
@@ -152,21 +154,27 @@ int pedoni_hip_kernel_times(PedoniModel* m, PedoniKernelTimes* out, int32_t rese
 const char* pedoni_hip_kernel_name(int32_t k);
 
 /* [ext] row-band sharding over several GPUs (no reference counterpart).
- * A model that owns neighbor-grid rows [row_begin, row_end) keeps agents of those rows
+ * A model that owns neighbor-grid rows [row_begin, row_end) keeps the agents of those rows
  * plus ghost copies of rows row_begin-1 and row_end.  Each tick, before sort/despawn:
- *   halo_pack   writes the full 24-byte state of the agents whose CURRENT cell row is
- *               row_begin-1 or row_begin (the "down" list, for the rank below) and
- *               row_end-1 or row_end (the "up" list, for the rank above) into `send`,
- *               a caller-owned DEVICE buffer of 2 * (header + cap_each records);
- *   (caller)    exchanges buffers with RCCL (torch.distributed all_gather_into_tensor);
- *   halo_unpack drops agents that left the band and last tick's ghosts, then places
- *               the "up" list of the rank below in FRONT of the kept agents and the
- *               "down" list of the rank above BEHIND them, so that the stable cell sort
- *               reproduces the single-GPU order bit for bit.
- * Forces are evaluated and integrated for owned rows only. */
+ *   halo_pack   writes the full 24-byte state of the owned agents whose CURRENT cell row
+ *               is row_begin-1 or row_begin (the "down" list, for the band below) and
+ *               row_end-1 or row_end (the "up" list, for the band above) into `send`, a
+ *               caller-owned DEVICE buffer of pedoni_hip_halo_bytes(cap_each) bytes:
+ *               [down: header, cap_each records][up: header, cap_each records];
+ *   (caller)    exchanges the buffers with RCCL (torch.distributed all_gather_into_tensor);
+ *   halo_unpack takes the whole buffer of the band below (its UP list is used) and of the
+ *               band above (its DOWN list), NULL at the outer bands, and stores the first
+ *               in FRONT of the model's own agents and the second BEHIND them, so that the
+ *               stable cell sort reproduces the single-GPU order bit for bit (lower bands
+ *               hold lower global indices).  Own agents are never moved; last tick's
+ *               ghosts were marked dead by update_states.
+ * Forces are evaluated and integrated for owned rows only.  An agent may cross at most
+ * one grid row per tick (checked; PEDONI_E_INVALID from owned_count otherwise). */
 #define PEDONI_HALO_HEADER_WORDS 4 /* u32 count, overflow flag, 2 reserved */
 #define PEDONI_HALO_RECORD_WORDS 6 /* pos.xy, vel.xy, desired_speed, destination */
-int pedoni_hip_set_band(PedoniModel* m, int32_t row_begin, int32_t row_end);
+/* set_band must be called on a model that holds no agents; `halo_cap` = capacity of each
+ * received list (agents), reserved in front of and behind the model's own agents. */
+int pedoni_hip_set_band(PedoniModel* m, int32_t row_begin, int32_t row_end, uint32_t halo_cap);
 int pedoni_hip_halo_bytes(uint32_t cap_each, uint64_t* bytes); /* size of one rank's buffer */
 int pedoni_hip_halo_pack(PedoniModel* m, void* send_dev, uint32_t cap_each);
 int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev,

@@ -291,7 +291,9 @@ class HipModel:
         return out
 
     def set_stream(self, stream_ptr: Optional[int]) -> None:
-        _check(self._lib, self._lib.pedoni_hip_set_stream(self._h, C.c_void_p(stream_ptr)))
+        """Run on the given hipStream_t (0 = HIP's default stream); None = library stream."""
+        _check(self._lib, self._lib.pedoni_hip_set_stream(
+            self._h, C.c_void_p(stream_ptr or 0), C.c_int32(1 if stream_ptr is None else 0)))
 
     def get_stream(self) -> int:
         s = C.c_void_p(None)
@@ -319,9 +321,9 @@ class HipModel:
         return out
 
     # -- sharding ----------------------------------------------------------------
-    def set_band(self, row_begin: int, row_end: int) -> None:
+    def set_band(self, row_begin: int, row_end: int, halo_cap: int) -> None:
         _check(self._lib, self._lib.pedoni_hip_set_band(self._h, C.c_int32(row_begin),
-                                                       C.c_int32(row_end)))
+                                                       C.c_int32(row_end), C.c_uint32(halo_cap)))
 
     @staticmethod
     def halo_bytes(cap_each: int) -> int:

@@ -69,22 +69,35 @@ __device__ __forceinline__ uint32_t pack_cell(uint32_t cx, uint32_t cy) { return
 // ---- K_KEY (PEDONI_K_BIN) ----------------------------------------------------------------
 // One thread per stored agent.  Slots [live, gap_end) hold agents despawned by earlier
 // ticks (the host only knows an upper bound of the live count) and are skipped.
+struct HaloIn {
+    uint32_t n_below; // agents received from the band below: stored at [base - n_below, base)
+    uint32_t n_above; // agents received from the band above: stored at [gap_end, gap_end + n_above)
+    uint32_t error;   // sticky: bit 0 = a sender overflowed its list, bit 1 = an agent left its band by > 1 row
+    uint32_t sharded; // 1 once the model exchanges halos
+};
+
 __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __restrict__ dest,
-                           uint32_t n_total, const uint32_t* __restrict__ live_count,
-                           uint32_t gap_end, FieldView field, GridView grid, int32_t band_lo,
-                           int32_t band_hi, const uint32_t* __restrict__ skey_old,
+                           uint32_t i0, uint32_t n_total, uint32_t base,
+                           const uint32_t* __restrict__ live_count, uint32_t gap_end,
+                           const HaloIn* __restrict__ halo, FieldView field, GridView grid,
+                           int32_t band_lo, int32_t band_hi, const uint32_t* __restrict__ skey_old,
                            int32_t force_general, uint32_t parity, SortFlags* __restrict__ flags,
                            uint32_t* __restrict__ key)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
         flags->far[parity ^ 1u] = 0;              // nobody reads the other tick's flag now
         if (force_general) atomicOr(&flags->far[parity], 1u);
     }
+    uint32_t i = i0 + t;
     if (i >= n_total) return;
     uint32_t live = *live_count;
+    uint32_t n_below = halo->n_below;
+    uint32_t app_end = halo->sharded ? gap_end + halo->n_above : n_total;
+    bool own = i >= base && i < live;
+    bool received = (i < base && i >= base - n_below) || (i >= gap_end && i < app_end);
     uint32_t k = DEAD;
-    if (i < live || i >= gap_end) {
+    if (own || received) {
         float2 p = pos[i];
         v2 pp = mk(p.x, p.y);
         int64_t c = cell_of(grid, pp);
@@ -93,7 +106,7 @@ __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __res
             // sharded runs keep only the band's rows plus one ghost row either side
             if (cy >= band_lo - 1 && cy <= band_hi) {
                 k = (uint32_t)c;
-                bool far = i >= gap_end;           // appended since the last pass
+                bool far = received;               // appended / exchanged since the last pass
                 if (!far && !force_general) {
                     uint32_t old = skey_old[i];
                     int32_t ox = (int32_t)(old & 0xffffu), oy = (int32_t)(old >> 16);
@@ -128,12 +141,12 @@ __device__ __forceinline__ CellRanges old_ranges(const uint32_t* __restrict__ cs
 // gather form: agent j scans the three old ranges of its NEW cell once, in index order;
 // rank = members before j = its place in the reference's per-cell list, and the last
 // member publishes the cell's count (cell_count was zeroed by the previous scan).
-__global__ void count_kernel(const uint32_t* __restrict__ key, uint32_t n_total, GridView grid,
-                             const uint32_t* __restrict__ cs_old,
+__global__ void count_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
+                             GridView grid, const uint32_t* __restrict__ cs_old,
                              const SortFlags* __restrict__ flags, uint32_t parity,
                              uint32_t* __restrict__ cell_count, uint32_t* __restrict__ rank)
 {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t j = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_total) return;
     uint32_t c = key[j];
     if (c == DEAD) return;
@@ -223,11 +236,11 @@ scan_reduce_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __rest
 
 // single block: exclusive scan of block_sums in place; total -> *total_out (and a copy)
 __global__ void __launch_bounds__(1024)
-scan_top_kernel(uint32_t* __restrict__ block_sums, uint32_t n_blocks,
+scan_top_kernel(uint32_t* __restrict__ block_sums, uint32_t n_blocks, uint32_t base,
                 uint32_t* __restrict__ total_out, uint32_t* __restrict__ total_out2)
 {
     __shared__ uint32_t lds[16];
-    uint32_t carry = 0;
+    uint32_t carry = base; // prefix values are absolute indices into the agent arrays
     for (uint32_t base = 0; base < n_blocks; base += 1024) {
         uint32_t i = base + threadIdx.x;
         uint32_t v = i < n_blocks ? block_sums[i] : 0;
@@ -285,11 +298,12 @@ __device__ __forceinline__ void move_agent(const SoA& a, uint32_t from, uint32_t
 }
 
 __global__ void write_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ rank,
-                             uint32_t n_total, GridView grid, const uint32_t* __restrict__ cs_new,
+                             uint32_t i0, uint32_t n_total, GridView grid,
+                             const uint32_t* __restrict__ cs_new,
                              const SortFlags* __restrict__ flags, uint32_t parity, SoA a,
                              uint32_t* __restrict__ slots)
 {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t j = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_total) return;
     uint32_t c = key[j];
     if (c == DEAD) return;
@@ -305,12 +319,13 @@ __global__ void write_kernel(const uint32_t* __restrict__ key, const uint32_t* _
 // ---- K_REORDER (general form only) --------------------------------------------------------
 // sfm.rs:66-75: an agent's place inside its cell is the number of cell-mates with a smaller
 // previous index; the slot list gives those indices in arbitrary (atomic arrival) order.
-__global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t n_total, GridView grid,
-                               const uint32_t* __restrict__ cs_new, const uint32_t* __restrict__ slots,
+__global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
+                               GridView grid, const uint32_t* __restrict__ cs_new,
+                               const uint32_t* __restrict__ slots,
                                const SortFlags* __restrict__ flags, uint32_t parity, SoA a)
 {
     if (flags->far[parity] == 0) return;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
     uint32_t k = key[i];
     if (k == DEAD) return;
@@ -347,7 +362,8 @@ struct ForceArgs {
     float2* pos_out;     // integrated state (write); may be null for acc-only
     float2* vel_out;
     float2* acc_out;     // optional: accelerations only (no integration)
-    const uint32_t* live_count;
+    const uint32_t* live_count; // absolute end index of the sorted agents
+    uint32_t base;              // absolute index of the first sorted agent
     const uint32_t* cell_start;
     const PedoniObstacleDev* obstacles;
     uint32_t n_obstacles;
@@ -420,7 +436,7 @@ __global__ void force_kernel_simple(ForceArgs a)
     if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
     __syncthreads();
 
-    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t id = a.base + blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = *a.live_count;
     if (id >= n) return;
 
@@ -462,7 +478,7 @@ __global__ void force_kernel_simple(ForceArgs a)
             }
         }
     } else {                                                 // :157-185
-        for (uint32_t i = 0; i < n; ++i) {
+        for (uint32_t i = a.base; i < n; ++i) {
             if (i != id) {
                 float2 pi = a.pos[i], vi = a.vel[i];
                 pair_force<MODE>(pos, e, mk(pi.x, pi.y), mk(vi.x, vi.y), acc, tab);
@@ -522,7 +538,7 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     float4* queue = queue_all[wave];
     unsigned char* owner_of = owner_all[wave];
     float2* e_lds = e_all[wave];
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t id = a.base + blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = *a.live_count;
     bool valid = id < n;
 
@@ -668,6 +684,112 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     pos = pos + (vel + vel_prev) * 0.05f;
     a.pos_out[id] = make_float2(pos.x, pos.y);
     a.vel_out[id] = make_float2(vel.x, vel.y);
+}
+
+// ---- halo exchange (no reference counterpart) -------------------------------
+// A band owns grid rows [lo, hi).  After update_states its owned agents sit in last pass's
+// sorted order, so the ones that can now be in rows {lo-1, lo} came from old rows lo, lo+1
+// -- one contiguous index range read off cell_start -- and likewise {hi-1, hi} from old
+// rows hi-2, hi-1.  One workgroup per direction compacts them, in index order, into a
+// record list: {pos.xy, vel.xy, desired_speed, destination}.
+struct HaloList {            // device layout of one direction's buffer
+    uint32_t count, flags, pad0, pad1;       // PEDONI_HALO_HEADER_WORDS
+    // followed by count records of PEDONI_HALO_RECORD_WORDS words
+};
+
+__global__ void __launch_bounds__(1024)
+halo_pack_kernel(const float2* __restrict__ pos, const float2* __restrict__ vel,
+                 const float* __restrict__ v0, const uint32_t* __restrict__ dest,
+                 const uint32_t* __restrict__ cs, GridView grid, int32_t band_lo, int32_t band_hi,
+                 uint32_t cap_each, uint32_t* __restrict__ send)
+{
+    __shared__ uint32_t lds[16];
+    const int dir = blockIdx.x;                           // 0 = down (for the band below), 1 = up
+    const uint32_t words_each = PEDONI_HALO_HEADER_WORDS + cap_each * PEDONI_HALO_RECORD_WORDS;
+    uint32_t* out = send + (size_t)dir * words_each;
+    uint32_t* rec = out + PEDONI_HALO_HEADER_WORDS;
+    int32_t row_a, row_b, want_a, want_b;
+    if (dir == 0) { row_a = band_lo; row_b = min(band_lo + 2, band_hi); want_a = band_lo - 1; want_b = band_lo; }
+    else          { row_a = max(band_hi - 2, band_lo); row_b = band_hi; want_a = band_hi - 1; want_b = band_hi; }
+    const bool has_neighbour = dir == 0 ? band_lo > 0 : band_hi < grid.rows;
+    uint32_t begin = cs[(int64_t)row_a * grid.cols], end = cs[(int64_t)row_b * grid.cols];
+    if (!has_neighbour) end = begin;
+    uint32_t written = 0, flags = 0;
+    for (uint32_t chunk = begin; chunk < end; chunk += blockDim.x) {
+        uint32_t i = chunk + threadIdx.x;
+        uint32_t take = 0;
+        float2 p = make_float2(0.0f, 0.0f);
+        if (i < end) {
+            p = pos[i];
+            if (p.x == p.x && p.y == p.y) {               // NaN agents are dropped by the next pass anyway
+                int32_t row = f32_as_i32(p.y / grid.unit);
+                take = (row == want_a || row == want_b) ? 1u : 0u;
+                if (row < band_lo - 1 || row > band_hi) flags |= 2u; // left the band by > 1 row
+            }
+        }
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan(take, lds, total);
+        uint32_t at = written + ex;
+        if (take) {
+            if (at < cap_each) {
+                uint32_t* r = rec + (size_t)at * PEDONI_HALO_RECORD_WORDS;
+                float2 v = vel[i];
+                r[0] = __float_as_uint(p.x); r[1] = __float_as_uint(p.y);
+                r[2] = __float_as_uint(v.x); r[3] = __float_as_uint(v.y);
+                r[4] = __float_as_uint(v0[i]); r[5] = dest[i];
+            } else {
+                flags |= 1u;                              // list overflow
+            }
+        }
+        written += total;
+    }
+    // block-wide OR of the flags
+    __shared__ uint32_t flag_or;
+    if (threadIdx.x == 0) flag_or = 0;
+    __syncthreads();
+    if (flags) atomicOr(&flag_or, flags);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = min(written, cap_each);
+        out[1] = flag_or;
+        out[2] = 0; out[3] = 0;
+    }
+}
+
+// Places the list of the band below right in front of the own agents ([base - n, base)) and
+// the list of the band above behind everything stored ([gap_end, gap_end + n)): with the
+// stable cell sort this reproduces the single-GPU order (lower bands hold lower indices).
+__global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
+                                   const uint32_t* __restrict__ from_above, uint32_t cap_each,
+                                   uint32_t base, uint32_t gap_end, float2* __restrict__ pos,
+                                   float2* __restrict__ vel, float* __restrict__ v0,
+                                   uint32_t* __restrict__ dest, HaloIn* __restrict__ halo)
+{
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_below = from_below ? min(from_below[0], cap_each) : 0u;
+    uint32_t n_above = from_above ? min(from_above[0], cap_each) : 0u;
+    if (t == 0) {
+        halo->n_below = n_below;
+        halo->n_above = n_above;
+        halo->sharded = 1;
+        uint32_t err = (from_below ? from_below[1] : 0u) | (from_above ? from_above[1] : 0u);
+        if (err) atomicOr(&halo->error, err);
+    }
+    const uint32_t* src = nullptr;
+    uint32_t at = 0;
+    if (t < n_below) {
+        src = from_below + PEDONI_HALO_HEADER_WORDS + (size_t)t * PEDONI_HALO_RECORD_WORDS;
+        at = base - n_below + t;
+    } else if (t >= cap_each && t - cap_each < n_above) {
+        uint32_t k = t - cap_each;
+        src = from_above + PEDONI_HALO_HEADER_WORDS + (size_t)k * PEDONI_HALO_RECORD_WORDS;
+        at = gap_end + k;
+    }
+    if (!src) return;
+    pos[at] = make_float2(__uint_as_float(src[0]), __uint_as_float(src[1]));
+    vel[at] = make_float2(__uint_as_float(src[2]), __uint_as_float(src[3]));
+    v0[at] = __uint_as_float(src[4]);
+    dest[at] = src[5];
 }
 
 } // namespace pedoni

@@ -121,8 +121,15 @@ struct PedoniModel {
     float2* d_acc = nullptr;
     uint32_t acc_cap = 0;
 
-    uint32_t n_upper = 0; // host upper bound of stored agents (live + stale + appended)
-    uint32_t gap_end = 0; // [live, gap_end) are stale slots, [gap_end, n_upper) appended
+    // absolute indices into the agent arrays: [base, live) sorted agents, [live, gap_end) stale
+    // slots, [gap_end, n_upper) appended since the last pass.  base = 0 unless the model is
+    // one band of a sharded run: then [base - halo_cap, base) is the landing zone of the list
+    // received from the band below (halo_unpack_kernel).
+    uint32_t base = 0;
+    uint32_t halo_cap = 0;
+    HaloIn* d_halo = nullptr;
+    uint32_t n_upper = 0; // host upper bound of the end of stored agents
+    uint32_t gap_end = 0;
     bool sorted = false;  // cell_start matches the current pos buffer
     bool force_simple = false; // PEDONI_FORCE_SIMPLE=1: one-lane-per-agent force kernel
     int ablate = 0;            // PEDONI_ABLATE bitmask: timing diagnostics only, results wrong
@@ -260,7 +267,7 @@ int run_scan(PedoniModel* m, uint32_t n, int zero_input, uint32_t* out)
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream,
                        m->d_scan_in, n, m->d_block_sums);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, m->stream, m->d_block_sums,
-                       n_blocks, out + n, m->d_live);
+                       n_blocks, m->base, out + n, m->d_live);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream,
                        m->d_scan_in, n, m->d_block_sums, out, zero_input);
     HIP_TRY(hipGetLastError());
@@ -273,10 +280,12 @@ inline uint32_t blocks_for(uint32_t n, uint32_t bs) { return std::max(1u, (n + b
 int sort_despawn(PedoniModel* m)
 {
     uint32_t n_total = m->n_upper;
+    const uint32_t i0 = m->base - m->halo_cap;     // first index a pass may have to look at
+    const uint32_t n_threads = n_total - i0;
     const int src = m->pv, dst = 1 - m->pv, vsrc = m->vd, vdst = 1 - m->vd;
     const uint32_t bs = 256;
-    if (n_total == 0) {
-        // nothing stored: live count 0, cell_start all zero
+    if (n_threads == 0) {
+        // nothing stored: live count 0, cell_start all zero (only reachable with base == 0)
         HIP_TRY(hipMemsetAsync(m->d_live, 0, sizeof(uint32_t), m->stream));
         if (m->opt.use_neighbor_grid)
             HIP_TRY(hipMemsetAsync(m->d_cs[m->cs], 0, (size_t)(m->n_cells + 1) * sizeof(uint32_t),
@@ -296,28 +305,28 @@ int sort_despawn(PedoniModel* m)
         {
             Timed t(m, PEDONI_K_BIN);
             if (t.rc) return t.rc;
-            hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0, m->stream,
-                               m->d_pos[src], m->d_dest[vsrc], n_total, m->d_live, m->gap_end,
-                               m->field, m->grid, m->band_lo, m->band_hi, m->d_skey[sk_old],
-                               force_general, parity, m->d_flags, m->d_key);
-            hipLaunchKernelGGL(count_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0,
-                               m->stream, m->d_key, n_total, m->grid, m->d_cs[cs_old],
+            hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0, m->stream,
+                               m->d_pos[src], m->d_dest[vsrc], i0, n_total, m->base, m->d_live,
+                               m->gap_end, m->d_halo, m->field, m->grid, m->band_lo, m->band_hi,
+                               m->d_skey[sk_old], force_general, parity, m->d_flags, m->d_key);
+            hipLaunchKernelGGL(count_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
+                               m->stream, m->d_key, i0, n_total, m->grid, m->d_cs[cs_old],
                                m->d_flags, parity, m->d_scan_in, m->d_rank);
         }
         TRY(run_scan(m, m->n_cells, /*zero_input=*/1, m->d_cs[cs_new]));
         {
             Timed t(m, PEDONI_K_SLOT);
             if (t.rc) return t.rc;
-            hipLaunchKernelGGL(write_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0,
-                               m->stream, m->d_key, m->d_rank, n_total, m->grid,
+            hipLaunchKernelGGL(write_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
+                               m->stream, m->d_key, m->d_rank, i0, n_total, m->grid,
                                m->d_cs[cs_new], m->d_flags, parity, soa, m->d_slots);
         }
         {
             Timed t(m, PEDONI_K_REORDER);
             if (t.rc) return t.rc;
-            hipLaunchKernelGGL(reorder_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0,
-                               m->stream, m->d_key, n_total, m->grid, m->d_cs[cs_new], m->d_slots,
-                               m->d_flags, parity, soa);
+            hipLaunchKernelGGL(reorder_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
+                               m->stream, m->d_key, i0, n_total, m->grid, m->d_cs[cs_new],
+                               m->d_slots, m->d_flags, parity, soa);
         }
         m->cs = cs_new;
         m->sk = sk_new;
@@ -348,6 +357,8 @@ int sort_despawn(PedoniModel* m)
     m->pv = dst;
     m->vd = vdst;
     m->gap_end = m->n_upper; // every stored agent is now either live (< *d_live) or stale
+    if (m->halo_cap) // the received lists are consumed: nothing in front of base any more
+        HIP_TRY(hipMemsetAsync(m->d_halo, 0, 2 * sizeof(uint32_t), m->stream));
     m->sorted = true;
     return PEDONI_OK;
 }
@@ -363,6 +374,7 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
     a.vel_out = acc_out ? nullptr : m->d_vel[1 - m->pv];
     a.acc_out = acc_out;
     a.live_count = m->d_live;
+    a.base = m->base;
     a.cell_start = m->d_cs[m->cs];
     a.obstacles = m->d_obstacles;
     a.n_obstacles = m->n_obstacles;
@@ -378,7 +390,7 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
 
 int launch_force(PedoniModel* m, float2* acc_out)
 {
-    uint32_t n = m->n_upper;
+    uint32_t n = m->n_upper - m->base;
     if (n == 0) return PEDONI_OK;
     uint32_t bs = m->opt.gpu_work_size > 0 ? (uint32_t)m->opt.gpu_work_size : 256u;
     ForceArgs a = force_args(m, acc_out);
@@ -406,7 +418,7 @@ int update_states(PedoniModel* m)
                     "update_states needs the sort/despawn pass of spawn_pedestrians first "
                     "(Simulator::tick order, lib.rs:85,90)");
     TRY(launch_force(m, nullptr));
-    if (m->n_upper) m->pv = 1 - m->pv;
+    if (m->n_upper > m->base) m->pv = 1 - m->pv;
     m->sorted = false;
     return PEDONI_OK;
 }
@@ -416,10 +428,10 @@ int sync_live_count(PedoniModel* m, uint32_t* out)
     HIP_TRY(hipMemcpyAsync(m->h_pinned, m->d_live, sizeof(uint32_t), hipMemcpyDeviceToHost,
                            m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    uint32_t live = m->h_pinned[0];
+    uint32_t live = m->h_pinned[0]; // absolute end index
     // tighten the host bound when nothing has been appended since the last pass
     if (m->gap_end == m->n_upper) m->n_upper = m->gap_end = live;
-    *out = live;
+    *out = live - m->base;
     return PEDONI_OK;
 }
 
@@ -587,6 +599,8 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
     C_HIP(hipMemset(m->d_live, 0, 4 * sizeof(uint32_t)));
     C_TRY(dev_alloc(&m->d_flags, 1));
     C_HIP(hipMemset(m->d_flags, 0, sizeof(SortFlags)));
+    C_TRY(dev_alloc(&m->d_halo, 1));
+    C_HIP(hipMemset(m->d_halo, 0, sizeof(HaloIn)));
     C_HIP(hipHostMalloc((void**)&m->h_pinned, 16 * sizeof(uint32_t), hipHostMallocDefault));
     C_TRY(ensure_capacity(m, std::max<uint32_t>(opt->initial_capacity, 1024)));
     C_HIP(hipDeviceSynchronize());
@@ -608,7 +622,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     hipFree(m->d_key); hipFree(m->d_rank); hipFree(m->d_slots);
     hipFree(m->d_scan_in); hipFree(m->d_cs[0]); hipFree(m->d_cs[1]); hipFree(m->d_block_sums);
     hipFree(m->d_skey[0]); hipFree(m->d_skey[1]); hipFree(m->d_flags);
-    hipFree(m->d_live); hipFree(m->d_acc);
+    hipFree(m->d_live); hipFree(m->d_acc); hipFree(m->d_halo);
     if (m->h_pinned) hipHostFree(m->h_pinned);
     hipFree(m->d_distance_map);
     for (float* p : m->d_pot) hipFree(p);
@@ -722,7 +736,9 @@ int pedoni_hip_download(PedoniModel* m, float* pos_xy, uint32_t* destination, fl
     uint32_t n1 = std::min(live, cap), n2 = std::min(appended, cap - n1);
     auto copy = [&](void* dst, const void* src, size_t elem) -> int {
         if (!dst) return PEDONI_OK;
-        if (n1) HIP_TRY(hipMemcpyAsync(dst, src, n1 * elem, hipMemcpyDeviceToHost, m->stream));
+        if (n1)
+            HIP_TRY(hipMemcpyAsync(dst, (const char*)src + (size_t)m->base * elem, n1 * elem,
+                                   hipMemcpyDeviceToHost, m->stream));
         if (n2)
             HIP_TRY(hipMemcpyAsync((char*)dst + (size_t)n1 * elem,
                                    (const char*)src + (size_t)m->gap_end * elem, n2 * elem,
@@ -733,6 +749,7 @@ int pedoni_hip_download(PedoniModel* m, float* pos_xy, uint32_t* destination, fl
     TRY(copy(vel_xy, m->d_vel[m->pv], sizeof(float2)));
     TRY(copy(desired_speed, m->d_v0[m->vd], sizeof(float)));
     TRY(copy(destination, m->d_dest[m->vd], sizeof(uint32_t)));
+    (void)0;
     HIP_TRY(hipStreamSynchronize(m->stream));
     return PEDONI_OK;
 }
@@ -760,11 +777,13 @@ int pedoni_hip_list_pedestrians(PedoniModel* m, PedoniPedestrian* out, uint32_t 
 int pedoni_hip_clear(PedoniModel* m)
 {
     TRY(bind(m));
-    HIP_TRY(hipMemsetAsync(m->d_live, 0, sizeof(uint32_t), m->stream));
-    if (m->opt.use_neighbor_grid)
-        HIP_TRY(hipMemsetAsync(m->d_cs[m->cs], 0, (size_t)(m->n_cells + 1) * sizeof(uint32_t),
-                               m->stream));
-    m->n_upper = m->gap_end = 0;
+    HIP_TRY(hipMemcpyAsync(m->d_live, &m->base, sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->opt.use_neighbor_grid) {
+        std::vector<uint32_t> fill((size_t)m->n_cells + 1, m->base);
+        HIP_TRY(hipMemcpy(m->d_cs[m->cs], fill.data(), fill.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    m->n_upper = m->gap_end = m->base;
     m->have_old = false;
     m->sorted = false;
     return PEDONI_OK;
@@ -797,7 +816,7 @@ int pedoni_hip_calc_accelerations(PedoniModel* m, float* acc_xy, uint32_t cap)
     TRY(bind(m));
     if (!m->sorted) return fail(PEDONI_E_INVALID, "calc_accelerations needs a sorted state");
     if (!acc_xy) return fail(PEDONI_E_INVALID, "null acc");
-    if (m->n_upper == 0) return PEDONI_OK;
+    if (m->n_upper == m->base) return PEDONI_OK;
     if (m->acc_cap < m->n_upper) {
         hipFree(m->d_acc);
         m->d_acc = nullptr;
@@ -808,16 +827,16 @@ int pedoni_hip_calc_accelerations(PedoniModel* m, float* acc_xy, uint32_t cap)
     uint32_t live = 0;
     TRY(sync_live_count(m, &live));
     uint32_t k = std::min(live, cap);
-    if (k) HIP_TRY(hipMemcpy(acc_xy, m->d_acc, (size_t)k * sizeof(float2), hipMemcpyDeviceToHost));
+    if (k) HIP_TRY(hipMemcpy(acc_xy, m->d_acc + m->base, (size_t)k * sizeof(float2), hipMemcpyDeviceToHost));
     return PEDONI_OK;
 }
 
-int pedoni_hip_set_stream(PedoniModel* m, void* hip_stream)
+int pedoni_hip_set_stream(PedoniModel* m, void* hip_stream, int32_t use_library_stream)
 {
     TRY(bind(m));
     TRY(drain_events(m));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    m->stream = hip_stream ? (hipStream_t)hip_stream : m->own_stream;
+    m->stream = use_library_stream ? m->own_stream : (hipStream_t)hip_stream;
     return PEDONI_OK;
 }
 
@@ -852,18 +871,23 @@ int pedoni_hip_kernel_times(PedoniModel* m, PedoniKernelTimes* out, int32_t rese
     return PEDONI_OK;
 }
 
-// ---- sharding stubs are in halo.hip-less form: implemented below -----------------------
-int pedoni_hip_set_band(PedoniModel* m, int32_t row_begin, int32_t row_end)
+// ---- row-band sharding ------------------------------------------------------------------------
+int pedoni_hip_set_band(PedoniModel* m, int32_t row_begin, int32_t row_end, uint32_t halo_cap)
 {
-    if (!m) return fail(PEDONI_E_INVALID, "null model");
+    TRY(bind(m));
     if (!m->opt.use_neighbor_grid)
         return fail(PEDONI_E_INVALID, "set_band: sharding needs the neighbor grid");
     if (row_begin < 0 || row_end > m->grid.rows || row_begin >= row_end)
         return fail(PEDONI_E_INVALID, "set_band: bad row range");
+    if (m->n_upper != m->base)
+        return fail(PEDONI_E_INVALID, "set_band: the model must hold no agents");
+    if (halo_cap > (1u << 24)) return fail(PEDONI_E_INVALID, "set_band: halo capacity too large");
     m->band_lo = row_begin;
     m->band_hi = row_end;
-    m->sorted = false;
-    return PEDONI_OK;
+    m->halo_cap = halo_cap;
+    m->base = halo_cap;
+    TRY(ensure_capacity(m, m->base + std::max<uint32_t>(m->opt.initial_capacity, 1024)));
+    return pedoni_hip_clear(m);
 }
 
 int pedoni_hip_halo_bytes(uint32_t cap_each, uint64_t* bytes)
@@ -875,22 +899,70 @@ int pedoni_hip_halo_bytes(uint32_t cap_each, uint64_t* bytes)
 
 int pedoni_hip_halo_pack(PedoniModel* m, void* send_dev, uint32_t cap_each)
 {
-    (void)send_dev; (void)cap_each;
     TRY(bind(m));
-    return fail(PEDONI_E_INVALID, "halo_pack: not implemented yet");
+    if (!send_dev) return fail(PEDONI_E_INVALID, "halo_pack: null buffer");
+    if (cap_each != m->halo_cap || cap_each == 0)
+        return fail(PEDONI_E_INVALID, "halo_pack: cap_each differs from set_band's halo capacity");
+    if (!m->have_old)
+        return fail(PEDONI_E_INVALID, "halo_pack: needs a sorted order (run sort_despawn once after loading)");
+    Timed t(m, PEDONI_K_HALO_PACK);
+    if (t.rc) return t.rc;
+    hipLaunchKernelGGL(halo_pack_kernel, dim3(2), dim3(1024), 0, m->stream, m->d_pos[m->pv],
+                       m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_cs[m->cs], m->grid,
+                       m->band_lo, m->band_hi, cap_each, (uint32_t*)send_dev);
+    HIP_TRY(hipGetLastError());
+    return PEDONI_OK;
 }
 
 int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const void* from_above_dev,
                            uint32_t cap_each)
 {
-    (void)from_below_dev; (void)from_above_dev; (void)cap_each;
     TRY(bind(m));
-    return fail(PEDONI_E_INVALID, "halo_unpack: not implemented yet");
+    if (cap_each != m->halo_cap || cap_each == 0)
+        return fail(PEDONI_E_INVALID, "halo_unpack: cap_each differs from set_band's halo capacity");
+    // the list from above lands behind everything stored: make room, tightening the host
+    // bound of the live count first when the arrays are about to run out
+    if ((uint64_t)m->n_upper + cap_each > m->cap && m->gap_end == m->n_upper) {
+        uint32_t live = 0;
+        TRY(sync_live_count(m, &live));
+    }
+    TRY(ensure_capacity(m, m->n_upper + cap_each));
+    const uint32_t words_each = PEDONI_HALO_HEADER_WORDS + cap_each * PEDONI_HALO_RECORD_WORDS;
+    // a rank's buffer is [down list][up list]: the band below sends us its UP list, the band
+    // above its DOWN list
+    const uint32_t* below = from_below_dev ? (const uint32_t*)from_below_dev + words_each : nullptr;
+    const uint32_t* above = (const uint32_t*)from_above_dev;
+    Timed t(m, PEDONI_K_HALO_UNPACK);
+    if (t.rc) return t.rc;
+    hipLaunchKernelGGL(halo_unpack_kernel, dim3(blocks_for(2 * cap_each, 256)), dim3(256), 0,
+                       m->stream, below, above, cap_each, m->base, m->n_upper, m->d_pos[m->pv],
+                       m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_halo);
+    HIP_TRY(hipGetLastError());
+    m->gap_end = m->n_upper;      // the above list starts here
+    m->n_upper += cap_each;       // host bound; the device knows the true count
+    m->sorted = false;
+    return PEDONI_OK;
 }
 
 int pedoni_hip_owned_count(PedoniModel* m, int32_t* count)
 {
-    return pedoni_hip_get_pedestrian_count(m, count);
+    TRY(bind(m));
+    if (!count) return fail(PEDONI_E_INVALID, "null count");
+    if (!m->opt.use_neighbor_grid || (!m->sorted && !m->have_old))
+        return pedoni_hip_get_pedestrian_count(m, count);
+    uint32_t lo = 0, hi = 0;
+    HaloIn h{};
+    HIP_TRY(hipMemcpyAsync(&lo, m->d_cs[m->cs] + (size_t)m->band_lo * m->grid.cols, sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(&hi, m->d_cs[m->cs] + (size_t)m->band_hi * m->grid.cols, sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(&h, m->d_halo, sizeof(HaloIn), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (h.error & 1u) return fail(PEDONI_E_CAPACITY, "halo list overflow: raise the halo capacity");
+    if (h.error & 2u)
+        return fail(PEDONI_E_INVALID, "an agent left its band by more than one grid row in one tick");
+    *count = (int32_t)(hi - lo);
+    return PEDONI_OK;
 }
 
 // ---- device math self-test -----------------------------------------------------------------
