@@ -139,11 +139,19 @@ def main() -> None:
 
     if not torch.cuda.is_available() or abi.device_count() < 1:
         sys.exit("bench.py needs a HIP device: the backend has no CPU fallback")
+    local_rank %= max(torch.cuda.device_count(), 1)   # (a rehearsal may share one card)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # "nccl" IS RCCL on ROCm; PEDONI_DIST_BACKEND=gloo only rehearses the code path
+        backend = os.environ.get("PEDONI_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)   # kernels + collective on one non-default stream
 
     G = args.gpus
     n_per = args.agents_per_gpu
@@ -162,14 +170,21 @@ def main() -> None:
     model = abi.HipModel(opt, (width, height), field.distance_map, field.potential_maps,
                          field.unit, obstacles, device=local_rank)
 
-    # this rank's agents: its own 1000 m band (2 m clear of the outer walls)
-    y_lo, y_hi = side * rank, side * (rank + 1)
+    if G > 1:
+        from pedoni_amd.sharded import ShardedModel
+        model.set_stream(stream.cuda_stream)
+        runner = ShardedModel(model, rank, G, dist, torch,
+                              expected_row_agents=int(width * 1.4 * DENSITY))
+        # this rank's agents: exactly its own band of grid rows (2 m clear of the outer walls)
+        y_lo, y_hi = runner.lo * 1.4 + 0.01, runner.hi * 1.4 - 0.01
+    else:
+        runner = None
+        y_lo, y_hi = 0.0, height
     pos, dest, v0, vel = uniform_crowd(
         n_per, (12.0, width - 12.0), (max(y_lo, 2.0), min(y_hi, height - 2.0)), seed=12345 + rank)
 
     if G > 1:
-        from pedoni_amd.sharded import ShardedModel
-        runner = ShardedModel(model, rank, G, dist, torch, expected_row_agents=int(width * 1.4 * DENSITY))
+        assert (runner.owner_of(pos[:, 1]) == rank).all()
         runner.load(pos, dest, v0, vel)
         step_fn = runner.tick_n
     else:

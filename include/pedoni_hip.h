@@ -179,6 +179,10 @@ int pedoni_hip_halo_bytes(uint32_t cap_each, uint64_t* bytes); /* size of one ra
 int pedoni_hip_halo_pack(PedoniModel* m, void* send_dev, uint32_t cap_each);
 int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev,
                            const void* from_above_dev, uint32_t cap_each);
+/* one sharded tick after the exchange, in one call: halo_unpack, sort/despawn,
+ * update_states, then halo_pack of the NEXT tick's lists into `send_dev` */
+int pedoni_hip_halo_tick(PedoniModel* m, const void* from_below_dev, const void* from_above_dev,
+                         void* send_dev, uint32_t cap_each);
 /* owned-agent count (excludes ghosts) */
 int pedoni_hip_owned_count(PedoniModel* m, int32_t* count);
 

@@ -944,6 +944,15 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
     return PEDONI_OK;
 }
 
+int pedoni_hip_halo_tick(PedoniModel* m, const void* from_below_dev, const void* from_above_dev,
+                         void* send_dev, uint32_t cap_each)
+{
+    TRY(pedoni_hip_halo_unpack(m, from_below_dev, from_above_dev, cap_each));
+    TRY(sort_despawn(m));
+    TRY(update_states(m));
+    return pedoni_hip_halo_pack(m, send_dev, cap_each);
+}
+
 int pedoni_hip_owned_count(PedoniModel* m, int32_t* count)
 {
     TRY(bind(m));

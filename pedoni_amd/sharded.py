@@ -35,8 +35,9 @@ def band_rows(n_rows: int, world: int) -> List[int]:
 
 
 def default_halo_cap(expected_row_agents: int) -> int:
-    """Two grid rows cross per list; 4x head-room over the expected population."""
-    return max(256, 4 * 2 * int(expected_row_agents))
+    """A list holds the owned agents of one boundary row plus the few that just crossed it:
+    1.5x the expected row population, rounded up to 256 (overflow is detected, not silent)."""
+    return max(256, -(-int(1.5 * expected_row_agents) // 256) * 256)
 
 
 class ShardedModel:
@@ -72,9 +73,16 @@ class ShardedModel:
             if dev.type == "cuda":
                 # kernels and the collective are ordered on one stream: no host sync per tick
                 model.set_stream(torch.cuda.current_stream().cuda_stream)
-
-            def _gather(send, recv):
-                dist.all_gather_into_tensor(self._recv_flat, send)
+            if dev.type == "cuda" and dist.get_backend() != "nccl":
+                # rehearsal backend (gloo): stage through the host; never used for timing
+                def _gather(send, recv):
+                    host = send.cpu()
+                    out = torch.zeros(world * host.numel(), dtype=host.dtype)
+                    dist.all_gather_into_tensor(out, host)
+                    self._recv_flat.copy_(out)
+            else:
+                def _gather(send, recv):
+                    dist.all_gather_into_tensor(self._recv_flat, send)   # RCCL over xGMI
             self._gather = _gather
         else:
             self._send, self._recv, self._gather = send, list(recv), gather
@@ -115,8 +123,17 @@ class ShardedModel:
         self.finish_tick()
 
     def tick_n(self, steps: int) -> None:
+        """`steps` ticks with two host calls per tick: the all-gather, then one fused
+        unpack + sort/despawn + update_states + pack-for-the-next-tick launch sequence."""
+        if steps <= 0:
+            return
+        m = self.model
+        below = self._recv[self.rank - 1].data_ptr() if self.rank > 0 else None
+        above = self._recv[self.rank + 1].data_ptr() if self.rank + 1 < self.world else None
+        self.pack()
         for _ in range(steps):
-            self.tick()
+            self._gather(self._send, self._recv)
+            m.halo_tick(below, above, self._send.data_ptr(), self.cap)
 
     def owned_count(self) -> int:
         return self.model.owned_count()
