@@ -106,8 +106,12 @@ __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __res
             // sharded runs keep only the band's rows plus one ghost row either side
             if (cy >= band_lo - 1 && cy <= band_hi) {
                 k = (uint32_t)c;
-                bool far = received;               // appended / exchanged since the last pass
-                if (!far && !force_general) {
+                // agents appended since the last pass force the general form -- except the
+                // exchanged lists of a sharded run, which can only land in the four boundary
+                // rows, where count/write/reorder use the general form anyway
+                bool boundary = halo->sharded && (cy <= band_lo || cy >= band_hi - 1);
+                bool far = received && !boundary;
+                if (!received && !force_general) {
                     uint32_t old = skey_old[i];
                     int32_t ox = (int32_t)(old & 0xffffu), oy = (int32_t)(old >> 16);
                     far = abs(cx - ox) > 1 || abs(cy - oy) > 1;
@@ -141,8 +145,18 @@ __device__ __forceinline__ CellRanges old_ranges(const uint32_t* __restrict__ cs
 // gather form: agent j scans the three old ranges of its NEW cell once, in index order;
 // rank = members before j = its place in the reference's per-cell list, and the last
 // member publishes the cell's count (cell_count was zeroed by the previous scan).
+// In a sharded run the cells of rows <= lo and >= hi-1 (ghost rows and the owned rows next
+// to them) also receive the exchanged lists, which sit outside the old ranges: those cells
+// always take the general form; all other rows keep the gather form.
+struct BandView { int32_t lo, hi, sharded; };
+__device__ __forceinline__ bool general_cell(const SortFlags* flags, uint32_t parity, const BandView& b,
+                                             int32_t cy)
+{
+    return flags->far[parity] != 0 || (b.sharded && (cy <= b.lo || cy >= b.hi - 1));
+}
+
 __global__ void count_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
-                             GridView grid, const uint32_t* __restrict__ cs_old,
+                             GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
                              const SortFlags* __restrict__ flags, uint32_t parity,
                              uint32_t* __restrict__ cell_count, uint32_t* __restrict__ rank)
 {
@@ -150,8 +164,8 @@ __global__ void count_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
     if (j >= n_total) return;
     uint32_t c = key[j];
     if (c == DEAD) return;
-    if (flags->far[parity] == 0) {
-        int32_t cy = (int32_t)(c / (uint32_t)grid.cols), cx = (int32_t)(c - (uint32_t)cy * (uint32_t)grid.cols);
+    int32_t cy = (int32_t)(c / (uint32_t)grid.cols), cx = (int32_t)(c - (uint32_t)cy * (uint32_t)grid.cols);
+    if (!general_cell(flags, parity, band, cy)) {
         CellRanges r = old_ranges(cs_old, grid, cx, cy);
         uint32_t before = 0, total = 0;
 #pragma unroll
@@ -298,7 +312,7 @@ __device__ __forceinline__ void move_agent(const SoA& a, uint32_t from, uint32_t
 }
 
 __global__ void write_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ rank,
-                             uint32_t i0, uint32_t n_total, GridView grid,
+                             uint32_t i0, uint32_t n_total, GridView grid, BandView band,
                              const uint32_t* __restrict__ cs_new,
                              const SortFlags* __restrict__ flags, uint32_t parity, SoA a,
                              uint32_t* __restrict__ slots)
@@ -308,8 +322,8 @@ __global__ void write_kernel(const uint32_t* __restrict__ key, const uint32_t* _
     uint32_t c = key[j];
     if (c == DEAD) return;
     uint32_t p = cs_new[c] + rank[j];
-    if (flags->far[parity] == 0) {                 // gather form: rank is final
-        uint32_t cy = c / (uint32_t)grid.cols, cx = c - cy * (uint32_t)grid.cols;
+    uint32_t cy = c / (uint32_t)grid.cols, cx = c - cy * (uint32_t)grid.cols;
+    if (!general_cell(flags, parity, band, (int32_t)cy)) { // gather form: rank is final
         move_agent(a, j, p, pack_cell(cx, cy));
     } else {                                       // general form: provisional slot
         slots[p] = j;
@@ -320,19 +334,20 @@ __global__ void write_kernel(const uint32_t* __restrict__ key, const uint32_t* _
 // sfm.rs:66-75: an agent's place inside its cell is the number of cell-mates with a smaller
 // previous index; the slot list gives those indices in arbitrary (atomic arrival) order.
 __global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
-                               GridView grid, const uint32_t* __restrict__ cs_new,
+                               GridView grid, BandView band, const uint32_t* __restrict__ cs_new,
                                const uint32_t* __restrict__ slots,
                                const SortFlags* __restrict__ flags, uint32_t parity, SoA a)
 {
-    if (flags->far[parity] == 0) return;
+    if (flags->far[parity] == 0 && !band.sharded) return;
     uint32_t i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
     uint32_t k = key[i];
     if (k == DEAD) return;
+    uint32_t cy = k / (uint32_t)grid.cols, cx = k - cy * (uint32_t)grid.cols;
+    if (!general_cell(flags, parity, band, (int32_t)cy)) return;
     uint32_t base = cs_new[k], end = cs_new[k + 1];
     uint32_t before = 0;
     for (uint32_t j = base; j < end; ++j) before += slots[j] < i ? 1u : 0u;
-    uint32_t cy = k / (uint32_t)grid.cols, cx = k - cy * (uint32_t)grid.cols;
     move_agent(a, i, base + before, pack_cell(cx, cy));
 }
 

@@ -257,19 +257,19 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
     return PEDONI_OK;
 }
 
-// exclusive scan of d_scan_in[0..n) -> out[0..n), total -> out[n] and d_live
-int run_scan(PedoniModel* m, uint32_t n, int zero_input, uint32_t* out)
+// exclusive scan of in[0..n) -> out[0..n) (+ base), total -> out[n] and d_live
+int run_scan(PedoniModel* m, uint32_t* in, uint32_t n, int zero_input, uint32_t* out)
 {
     Timed t(m, PEDONI_K_SCAN);
     if (t.rc) return t.rc;
     uint32_t n_blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (n_blocks == 0) n_blocks = 1;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream,
-                       m->d_scan_in, n, m->d_block_sums);
+                       in, n, m->d_block_sums);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, m->stream, m->d_block_sums,
                        n_blocks, m->base, out + n, m->d_live);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream,
-                       m->d_scan_in, n, m->d_block_sums, out, zero_input);
+                       in, n, m->d_block_sums, out, zero_input);
     HIP_TRY(hipGetLastError());
     return PEDONI_OK;
 }
@@ -300,6 +300,11 @@ int sort_despawn(PedoniModel* m)
         // the gather form needs last tick's order and 16-bit cell coordinates
         const bool packable = m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
         const int force_general = (!m->have_old || !packable || m->sort_general) ? 1 : 0;
+        const BandView band{m->band_lo, m->band_hi, m->halo_cap ? 1 : 0};
+        // a band only ever touches the cells of rows lo-1 .. hi: scan just those
+        const int32_t row0 = std::max(m->band_lo - 1, 0), row1 = std::min(m->band_hi + 1, m->grid.rows);
+        const uint32_t c0 = (uint32_t)row0 * (uint32_t)m->grid.cols;
+        const uint32_t n_scan = (uint32_t)(row1 - row0) * (uint32_t)m->grid.cols;
         SoA soa{m->d_pos[src], m->d_vel[src], m->d_v0[vsrc], m->d_dest[vsrc],
                 m->d_pos[dst], m->d_vel[dst], m->d_v0[vdst], m->d_dest[vdst], m->d_skey[sk_new]};
         {
@@ -310,22 +315,22 @@ int sort_despawn(PedoniModel* m)
                                m->gap_end, m->d_halo, m->field, m->grid, m->band_lo, m->band_hi,
                                m->d_skey[sk_old], force_general, parity, m->d_flags, m->d_key);
             hipLaunchKernelGGL(count_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
-                               m->stream, m->d_key, i0, n_total, m->grid, m->d_cs[cs_old],
+                               m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
                                m->d_flags, parity, m->d_scan_in, m->d_rank);
         }
-        TRY(run_scan(m, m->n_cells, /*zero_input=*/1, m->d_cs[cs_new]));
+        TRY(run_scan(m, m->d_scan_in + c0, n_scan, /*zero_input=*/1, m->d_cs[cs_new] + c0));
         {
             Timed t(m, PEDONI_K_SLOT);
             if (t.rc) return t.rc;
             hipLaunchKernelGGL(write_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
-                               m->stream, m->d_key, m->d_rank, i0, n_total, m->grid,
+                               m->stream, m->d_key, m->d_rank, i0, n_total, m->grid, band,
                                m->d_cs[cs_new], m->d_flags, parity, soa, m->d_slots);
         }
         {
             Timed t(m, PEDONI_K_REORDER);
             if (t.rc) return t.rc;
             hipLaunchKernelGGL(reorder_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
-                               m->stream, m->d_key, i0, n_total, m->grid, m->d_cs[cs_new],
+                               m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_new],
                                m->d_slots, m->d_flags, parity, soa);
         }
         m->cs = cs_new;
@@ -343,7 +348,7 @@ int sort_despawn(PedoniModel* m)
         // d_key keeps the flags: the scan may not zero what compact still reads
         HIP_TRY(hipMemcpyAsync(m->d_key, m->d_scan_in, (size_t)n_total * sizeof(uint32_t),
                                hipMemcpyDeviceToDevice, m->stream));
-        TRY(run_scan(m, n_total, /*zero_input=*/0, m->d_cs[0]));
+        TRY(run_scan(m, m->d_scan_in, n_total, /*zero_input=*/0, m->d_cs[0]));
         {
             Timed t(m, PEDONI_K_REORDER);
             if (t.rc) return t.rc;
