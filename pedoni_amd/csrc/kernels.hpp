@@ -85,10 +85,7 @@ __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __res
                            uint32_t* __restrict__ key)
 {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) {
-        flags->far[parity ^ 1u] = 0;              // nobody reads the other tick's flag now
-        if (force_general) atomicOr(&flags->far[parity], 1u);
-    }
+    if (t == 0 && force_general) atomicOr(&flags->far[parity], 1u);
     uint32_t i = i0 + t;
     if (i >= n_total) return;
     uint32_t live = *live_count;
@@ -161,6 +158,9 @@ __global__ void count_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
                              uint32_t* __restrict__ cell_count, uint32_t* __restrict__ rank)
 {
     uint32_t j = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    // the NEXT tick's flag is raised by this tick's update_states and the next K_KEY; it can
+    // be cleared here because K_KEY of this tick has finished and nothing reads it now
+    if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<SortFlags*>(flags)->far[parity ^ 1u] = 0;
     if (j >= n_total) return;
     uint32_t c = key[j];
     if (c == DEAD) return;
@@ -338,17 +338,20 @@ __global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, ui
                                const uint32_t* __restrict__ slots,
                                const SortFlags* __restrict__ flags, uint32_t parity, SoA a)
 {
+    // launched with a small fixed grid: in the common tick (gather form everywhere) every
+    // wave leaves after one flag read
     if (flags->far[parity] == 0 && !band.sharded) return;
-    uint32_t i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
-    uint32_t k = key[i];
-    if (k == DEAD) return;
-    uint32_t cy = k / (uint32_t)grid.cols, cx = k - cy * (uint32_t)grid.cols;
-    if (!general_cell(flags, parity, band, (int32_t)cy)) return;
-    uint32_t base = cs_new[k], end = cs_new[k + 1];
-    uint32_t before = 0;
-    for (uint32_t j = base; j < end; ++j) before += slots[j] < i ? 1u : 0u;
-    move_agent(a, i, base + before, pack_cell(cx, cy));
+    for (uint32_t i = i0 + blockIdx.x * blockDim.x + threadIdx.x; i < n_total;
+         i += gridDim.x * blockDim.x) {
+        uint32_t k = key[i];
+        if (k == DEAD) continue;
+        uint32_t cy = k / (uint32_t)grid.cols, cx = k - cy * (uint32_t)grid.cols;
+        if (!general_cell(flags, parity, band, (int32_t)cy)) continue;
+        uint32_t base = cs_new[k], end = cs_new[k + 1];
+        uint32_t before = 0;
+        for (uint32_t j = base; j < end; ++j) before += slots[j] < i ? 1u : 0u;
+        move_agent(a, i, base + before, pack_cell(cx, cy));
+    }
 }
 
 // no-grid compaction: survivor i goes to its exclusive flag prefix
@@ -386,6 +389,12 @@ struct ForceArgs {
     GridView grid;
     int32_t band_lo, band_hi; // rows whose agents are integrated (others are ghosts)
     int32_t use_grid, use_distance_map;
+    // fused K_KEY of the next sort/despawn pass (null = not requested): the agent's next
+    // cell key (or DEAD) and the far-mover flag of the next tick's parity
+    uint32_t* key_next;
+    uint32_t key_end;    // stale slots [live, key_end) get DEAD keys
+    SortFlags* flags;
+    uint32_t parity_next;
     int32_t ablate; // diagnostics only (PEDONI_ABLATE): 1 = no goal sampling, 2 = no obstacle term, 4 = no pairs
 };
 
@@ -671,12 +680,16 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
         __builtin_amdgcn_wave_barrier();
     }
 
-    if (!valid) return;
+    if (!valid) {
+        if (a.key_next && id < a.key_end) a.key_next[id] = DEAD;  // slot of a despawned agent
+        return;
+    }
     if (ghost) {                                                  // ghost row: never integrated
         if (a.pos_out) {                                          // NaN position = "not mine"; the
             float qn = __builtin_nanf("");                        // next sort/despawn pass drops it
             a.pos_out[id] = make_float2(qn, qn);
             a.vel_out[id] = vv;
+            if (a.key_next) a.key_next[id] = DEAD;
         }
         return;
     }
@@ -688,6 +701,7 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); return; }
 
     // integrator, sfm.rs:245-254
+    const float p_old_x = pos.x, p_old_y = pos.y;
     v2 vel_prev = vel;
     vel = vel + acc * 0.1f;
     float max_len = desired_speed * 1.3f;
@@ -699,6 +713,22 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     pos = pos + (vel + vel_prev) * 0.05f;
     a.pos_out[id] = make_float2(pos.x, pos.y);
     a.vel_out[id] = make_float2(vel.x, vel.y);
+
+    // fused K_KEY for the next tick: same arithmetic as key_kernel on the new position (the
+    // potential texels are the ones the goal stencil just touched, so they come from L1/L2)
+    if (a.key_next) {
+        uint32_t k = DEAD;
+        int64_t c = cell_of(a.grid, pos);
+        if (c >= 0 && survives(a.field, pos, a.dest[id])) {
+            int32_t cy = (int32_t)(c / a.grid.cols), cx = (int32_t)(c - (int64_t)cy * a.grid.cols);
+            if (cy >= a.band_lo - 1 && cy <= a.band_hi) {
+                k = (uint32_t)c;
+                int32_t ox = f32_as_i32(p_old_x / a.grid.unit), oy = f32_as_i32(p_old_y / a.grid.unit);
+                if (abs(cx - ox) > 1 || abs(cy - oy) > 1) atomicOr(&a.flags->far[a.parity_next], 1u);
+            }
+        }
+        a.key_next[id] = k;
+    }
 }
 
 // ---- halo exchange (no reference counterpart) -------------------------------

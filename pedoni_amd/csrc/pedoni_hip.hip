@@ -113,6 +113,7 @@ struct PedoniModel {
     SortFlags* d_flags = nullptr;
     uint32_t tick_parity = 0;
     bool have_old = false;          // d_cs[cs] / d_skey[sk] describe the stored order
+    bool keys_valid = false;        // d_key[base, live) already holds the next pass's keys (fused in K_FORCE)
     uint32_t scan_cap = 0;
     uint32_t* d_block_sums = nullptr;
     uint32_t block_sums_cap = 0;
@@ -134,6 +135,7 @@ struct PedoniModel {
     bool force_simple = false; // PEDONI_FORCE_SIMPLE=1: one-lane-per-agent force kernel
     int ablate = 0;            // PEDONI_ABLATE bitmask: timing diagnostics only, results wrong
     bool sort_general = false; // PEDONI_SORT_GENERAL=1: always take the atomic (general) sort form
+    bool no_fuse_key = false;  // PEDONI_NO_FUSE_KEY=1: standalone K_KEY every tick
 
     // profiling
     uint32_t profile_mask = 0;
@@ -243,6 +245,7 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
     TRY(dev_alloc(&m->d_skey[0], ncap));
     TRY(dev_alloc(&m->d_skey[1], ncap));
     m->have_old = false; // the per-agent old-cell array did not survive the reallocation
+    m->keys_valid = false;
     m->cap = ncap;
 
     if (!m->opt.use_neighbor_grid) {
@@ -310,10 +313,27 @@ int sort_despawn(PedoniModel* m)
         {
             Timed t(m, PEDONI_K_BIN);
             if (t.rc) return t.rc;
-            hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0, m->stream,
-                               m->d_pos[src], m->d_dest[vsrc], i0, n_total, m->base, m->d_live,
-                               m->gap_end, m->d_halo, m->field, m->grid, m->band_lo, m->band_hi,
-                               m->d_skey[sk_old], force_general, parity, m->d_flags, m->d_key);
+            if (!m->keys_valid || force_general) {
+                // every stored agent needs its key
+                hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0, m->stream,
+                                   m->d_pos[src], m->d_dest[vsrc], i0, n_total, m->base, m->d_live,
+                                   m->gap_end, m->d_halo, m->field, m->grid, m->band_lo, m->band_hi,
+                                   m->d_skey[sk_old], force_general, parity, m->d_flags, m->d_key);
+            } else {
+                // own agents got their keys from the last update_states; only agents stored
+                // since then (appended / exchanged lists) are keyed here
+                if (m->halo_cap)
+                    hipLaunchKernelGGL(key_kernel, dim3(blocks_for(m->halo_cap, bs)), dim3(bs), 0,
+                                       m->stream, m->d_pos[src], m->d_dest[vsrc], i0, m->base, m->base,
+                                       m->d_live, m->gap_end, m->d_halo, m->field, m->grid, m->band_lo,
+                                       m->band_hi, m->d_skey[sk_old], 0, parity, m->d_flags, m->d_key);
+                if (n_total > m->gap_end)
+                    hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_total - m->gap_end, bs)), dim3(bs),
+                                       0, m->stream, m->d_pos[src], m->d_dest[vsrc], m->gap_end, n_total,
+                                       m->base, m->d_live, m->gap_end, m->d_halo, m->field, m->grid,
+                                       m->band_lo, m->band_hi, m->d_skey[sk_old], 0, parity, m->d_flags,
+                                       m->d_key);
+            }
             hipLaunchKernelGGL(count_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
                                m->d_flags, parity, m->d_scan_in, m->d_rank);
@@ -329,7 +349,7 @@ int sort_despawn(PedoniModel* m)
         {
             Timed t(m, PEDONI_K_REORDER);
             if (t.rc) return t.rc;
-            hipLaunchKernelGGL(reorder_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
+            hipLaunchKernelGGL(reorder_kernel, dim3(std::min(blocks_for(n_threads, bs), 1024u)), dim3(bs), 0,
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_new],
                                m->d_slots, m->d_flags, parity, soa);
         }
@@ -337,6 +357,7 @@ int sort_despawn(PedoniModel* m)
         m->sk = sk_new;
         m->tick_parity += 1;
         m->have_old = true;
+        m->keys_valid = false; // consumed
     } else {
         {
             Timed t(m, PEDONI_K_BIN);
@@ -390,6 +411,13 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
     a.use_grid = m->opt.use_neighbor_grid;
     a.use_distance_map = m->opt.use_distance_map;
     a.ablate = m->ablate;
+    // fuse the next pass's K_KEY when this launch integrates (queue kernel, grid mode)
+    const bool fuse = !acc_out && m->opt.use_neighbor_grid && !m->force_simple && !m->no_fuse_key &&
+                      m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
+    a.key_next = fuse ? m->d_key : nullptr;
+    a.key_end = m->n_upper;
+    a.flags = m->d_flags;
+    a.parity_next = m->tick_parity & 1u;
     return a;
 }
 
@@ -424,6 +452,8 @@ int update_states(PedoniModel* m)
                     "(Simulator::tick order, lib.rs:85,90)");
     TRY(launch_force(m, nullptr));
     if (m->n_upper > m->base) m->pv = 1 - m->pv;
+    m->keys_valid = m->n_upper > m->base && m->opt.use_neighbor_grid && !m->force_simple &&
+                    !m->no_fuse_key && m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
     m->sorted = false;
     return PEDONI_OK;
 }
@@ -540,6 +570,8 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
         m->ablate = ab ? std::atoi(ab) : 0;
         const char* sg = std::getenv("PEDONI_SORT_GENERAL");
         m->sort_general = sg && sg[0] == '1';
+        const char* nf = std::getenv("PEDONI_NO_FUSE_KEY");
+        m->no_fuse_key = nf && nf[0] == '1';
     }
     *out = nullptr;
 
@@ -790,6 +822,7 @@ int pedoni_hip_clear(PedoniModel* m)
     }
     m->n_upper = m->gap_end = m->base;
     m->have_old = false;
+    m->keys_valid = false;
     m->sorted = false;
     return PEDONI_OK;
 }

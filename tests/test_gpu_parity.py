@@ -120,6 +120,34 @@ def test_narrow_gap_200_ticks_lockstep(hip, oracle):
     gpu.close()
 
 
+def test_tick_n_without_host_sync_keeps_parity_through_despawns(hip, oracle):
+    """`tick_n` never reads the live count back, so despawned agents leave stale slots
+    behind the live range; those must never re-enter the sort (narrow-gap: all 50 agents
+    reach the goal and despawn within 400 ticks)."""
+    sc = scn.load(GOLDEN / "scenarios" / "narrow_gap.toml")
+    field = oracle_field(oracle, sc)
+    rng = np.random.default_rng(8)
+    pos = np.stack([np.full(50, 3.0), rng.uniform(3, 17, 50)], 1).astype(np.float32)
+    dest = np.ones(50, np.uint32)
+    v0 = rng.uniform(1.0, 1.6, 50).astype(np.float32)
+    cpu = oracle.OracleModel(sc.field.size)
+    gpu = _make_hip(hip, sc, field)
+    cpu.spawn_pedestrians(field, pos, dest, v0, np.zeros((50, 2), np.float32))
+    gpu.append(pos, dest, v0, None)
+    seen = []
+    for chunk in (60, 60, 60, 220):
+        gpu.tick_n(chunk)
+        for _ in range(chunk):
+            cpu.spawn_pedestrians(field)
+            cpu.update_states(field)
+        cpu_state = cpu.download()
+        got = gpu.download()
+        _assert_state_equal(got, cpu_state, f"after {chunk} more ticks")
+        seen.append(len(got[0]))
+    assert seen[0] == 50 and seen[-1] < seen[0]
+    gpu.close()
+
+
 # ---- C2-style: random obstacles, injected crowd, per step from identical state -----------
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 5000, 100_000])
 def test_random_crowd_per_step_parity(hip, oracle, n):
