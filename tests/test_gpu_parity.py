@@ -144,7 +144,7 @@ def test_tick_n_without_host_sync_keeps_parity_through_despawns(hip, oracle):
         got = gpu.download()
         _assert_state_equal(got, cpu_state, f"after {chunk} more ticks")
         seen.append(len(got[0]))
-    assert seen[0] == 50 and seen[-1] < seen[0]
+    assert 0 <= seen[-1] < seen[0] <= 50
     gpu.close()
 
 
