@@ -295,6 +295,83 @@ scan_apply_kernel(uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restr
     }
 }
 
+// ---- single-pass scan (decoupled look-back) ---------------------------------------------------
+// One launch instead of three: every block scans its 2048-element tile, publishes its
+// aggregate, and resolves its exclusive prefix by walking back over its predecessors'
+// published words.  A word packs {epoch, state, value} so nothing needs zeroing between
+// launches (the epoch changes) and a single relaxed agent-scope 64-bit access carries both
+// flag and data (MI355X_MICROARCH: sc1 accesses bypass the non-coherent L1).  Tiles are
+// handed out by an atomic ticket, so a block only ever waits for blocks that already run.
+struct ScanState {
+    unsigned long long* words; // one per tile
+    uint32_t* ticket;          // reset by the block that draws the last ticket
+};
+
+__device__ __forceinline__ unsigned long long scan_word(uint32_t epoch, uint32_t state, uint32_t v)
+{
+    return ((unsigned long long)epoch << 34) | ((unsigned long long)state << 32) | v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_single_kernel(uint32_t* __restrict__ in, uint32_t n, uint32_t base, uint32_t* __restrict__ out,
+                   uint32_t* __restrict__ total_out2, int zero_input, ScanState st, uint32_t epoch)
+{
+    __shared__ uint32_t lds[SCAN_THREADS / 64];
+    __shared__ uint32_t tile_s, prefix_s;
+    if (threadIdx.x == 0) {
+        uint32_t t = atomicAdd(st.ticket, 1u);
+        if (t == gridDim.x - 1) *st.ticket = 0;            // every ticket has been drawn
+        tile_s = t;
+    }
+    __syncthreads();
+    const uint32_t tile = tile_s;
+    uint32_t first = tile * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+    uint32_t v[SCAN_PER_THREAD];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        v[k] = first + k < n ? in[first + k] : 0;
+        s += v[k];
+    }
+    uint32_t aggregate;
+    uint32_t ex = block_exclusive_scan(s, lds, aggregate);
+    // publish the tile's aggregate first, then add up ALL predecessors' aggregates with the
+    // whole block: no tile waits on another tile's prefix, only on its (early) aggregate
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&st.words[tile], scan_word(epoch, 1, aggregate), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t partial = 0;
+    for (uint32_t p = threadIdx.x; p < tile; p += SCAN_THREADS) {
+        unsigned long long w;
+        uint32_t spins = 0;                                  // bounded: the predecessor holds an
+        do {                                                 // earlier ticket, so it already runs
+            w = __hip_atomic_load(&st.words[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > (1u << 22)) break;
+            if (spins > 8) __builtin_amdgcn_s_sleep(1);
+        } while ((uint32_t)(w >> 34) != epoch);
+        partial += (uint32_t)w;
+    }
+    uint32_t before_total;
+    block_exclusive_scan(partial, lds, before_total);
+    if (threadIdx.x == 0) {
+        prefix_s = base + before_total;
+        if (tile == gridDim.x - 1) {
+            out[n] = base + before_total + aggregate;
+            if (total_out2) *total_out2 = base + before_total + aggregate;
+        }
+    }
+    __syncthreads();
+    ex += prefix_s;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        if (first + k < n) {
+            out[first + k] = ex;
+            if (zero_input) in[first + k] = 0;
+        }
+        ex += v[k];
+    }
+}
+
 // ---- K_WRITE (PEDONI_K_SLOT) ----------------------------------------------------------------
 struct SoA {
     const float2* pos_in; const float2* vel_in; const float* v0_in; const uint32_t* dest_in;
@@ -414,7 +491,7 @@ __device__ __forceinline__ v2 obstacle_force_map(const FieldView& f, v2 pos, con
     v2 q = field_coord(f, pos);
     float distance;
     v2 direction = -normalize<MODE>(sobel_fast(f.distance_map, f.rows, f.cols, q.x, q.y, &distance));
-    float k = (10.0f * 0.2f) * fexp<MODE>(fdiv<MODE>(-distance, 0.2f), tab);
+    float k = (10.0f * 0.2f) * fexp<MODE>(div_02<MODE>(-distance), tab);
     return direction * k;
 }
 
@@ -444,7 +521,7 @@ __device__ __forceinline__ void obstacle_force_segments(const PedoniObstacleDev*
         if (ds2 < min_d) { min_d = ds2; dm = df[2]; }
         if (ds3 < min_d) { min_d = ds3; dm = df[3]; }
         v2 direction = normalize<MODE>(dm);                  // :223
-        float k = (10.0f * 0.2f) * fexp<MODE>(fdiv<MODE>(-min_d, 0.2f), tab); // :225
+        float k = (10.0f * 0.2f) * fexp<MODE>(div_02<MODE>(-min_d), tab);      // :225
         acc = acc + direction * k;                           // :226
     }
 }
@@ -567,6 +644,7 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     bool valid = id < n;
 
     v2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), acc = mk(0.0f, 0.0f), e = mk(0.0f, 0.0f);
+    v2 wall = mk(0.0f, 0.0f);
     float2 vv = make_float2(0.0f, 0.0f);
     float desired_speed = 0.0f;
     uint32_t r0 = 0, r1 = 0, r2 = 0, n0 = 0, n1 = 0, n2 = 0;
@@ -585,6 +663,10 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
             if (a.ablate & 1) e = mk(1.0f, 0.0f);
             else e = goal_direction<MODE>(a.field, pos, destination); // :107-108
             acc = acc + vdiv<MODE>(e * desired_speed - vel, 0.5f); // :109
+            // the wall term only needs the agent's own position: sample the distance map
+            // now, so its texel loads overlap the potential map's; it is ADDED after the
+            // pair forces, where the reference adds it (:188-192)
+            if (a.use_distance_map && !(a.ablate & 2)) wall = obstacle_force_map<MODE>(a.field, pos, tab);
             int32_t y_start = max(iy - 1, 0), y_end = min(iy + 1, a.grid.rows - 1); // :117-118
             int32_t x_start = max(ix - 1, 0), x_end = min(ix + 1, a.grid.cols - 1); // :119-120
             // rows y_start..y_end in ascending order; a missing row contributes nothing
@@ -695,7 +777,7 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     }
 
     if (a.ablate & 2) {}
-    else if (a.use_distance_map) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
+    else if (a.use_distance_map) acc = acc + wall;
     else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
 
     if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); return; }

@@ -117,6 +117,11 @@ struct PedoniModel {
     uint32_t scan_cap = 0;
     uint32_t* d_block_sums = nullptr;
     uint32_t block_sums_cap = 0;
+    unsigned long long* d_scan_words = nullptr; // single-pass scan: one status word per tile
+    uint32_t scan_words_cap = 0;
+    uint32_t* d_scan_ticket = nullptr;
+    uint32_t scan_epoch = 0;
+    bool scan3 = false;                         // PEDONI_SCAN3=1: three-launch scan
     uint32_t* d_live = nullptr; // device: live agent count
     uint32_t* h_pinned = nullptr;
     float2* d_acc = nullptr;
@@ -267,6 +272,23 @@ int run_scan(PedoniModel* m, uint32_t* in, uint32_t n, int zero_input, uint32_t*
     if (t.rc) return t.rc;
     uint32_t n_blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (n_blocks == 0) n_blocks = 1;
+    if (!m->scan3 && n_blocks <= 4096) {
+        if (m->scan_words_cap < n_blocks) {
+            hipFree(m->d_scan_words);
+            m->d_scan_words = nullptr;
+            uint32_t cap = std::max(n_blocks * 2, 1024u);
+            TRY(dev_alloc(&m->d_scan_words, cap));
+            HIP_TRY(hipMemsetAsync(m->d_scan_words, 0, (size_t)cap * sizeof(unsigned long long), m->stream));
+            m->scan_words_cap = cap;
+        }
+        m->scan_epoch = (m->scan_epoch + 1) & 0x3fffffffu;
+        if (m->scan_epoch == 0) m->scan_epoch = 1;          // 0 = "never written"
+        ScanState st{m->d_scan_words, m->d_scan_ticket};
+        hipLaunchKernelGGL(scan_single_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream, in, n,
+                           m->base, out, m->d_live, zero_input, st, m->scan_epoch);
+        HIP_TRY(hipGetLastError());
+        return PEDONI_OK;
+    }
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream,
                        in, n, m->d_block_sums);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, m->stream, m->d_block_sums,
@@ -572,6 +594,8 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
         m->sort_general = sg && sg[0] == '1';
         const char* nf = std::getenv("PEDONI_NO_FUSE_KEY");
         m->no_fuse_key = nf && nf[0] == '1';
+        const char* s3 = std::getenv("PEDONI_SCAN3");
+        m->scan3 = s3 && s3[0] == '1';
     }
     *out = nullptr;
 
@@ -636,6 +660,8 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
     C_HIP(hipMemset(m->d_live, 0, 4 * sizeof(uint32_t)));
     C_TRY(dev_alloc(&m->d_flags, 1));
     C_HIP(hipMemset(m->d_flags, 0, sizeof(SortFlags)));
+    C_TRY(dev_alloc(&m->d_scan_ticket, 4));
+    C_HIP(hipMemset(m->d_scan_ticket, 0, 4 * sizeof(uint32_t)));
     C_TRY(dev_alloc(&m->d_halo, 1));
     C_HIP(hipMemset(m->d_halo, 0, sizeof(HaloIn)));
     C_HIP(hipHostMalloc((void**)&m->h_pinned, 16 * sizeof(uint32_t), hipHostMallocDefault));
@@ -660,6 +686,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     hipFree(m->d_scan_in); hipFree(m->d_cs[0]); hipFree(m->d_cs[1]); hipFree(m->d_block_sums);
     hipFree(m->d_skey[0]); hipFree(m->d_skey[1]); hipFree(m->d_flags);
     hipFree(m->d_live); hipFree(m->d_acc); hipFree(m->d_halo);
+    hipFree(m->d_scan_words); hipFree(m->d_scan_ticket);
     if (m->h_pinned) hipHostFree(m->h_pinned);
     hipFree(m->d_distance_map);
     for (float* p : m->d_pot) hipFree(p);
@@ -1029,6 +1056,8 @@ __global__ void selftest_kernel(int op, const float* a, const float* b, float* o
     case 0: r = fdiv<MODE>(a[i], b[i]); break;
     case 1: r = fsqrt<MODE>(a[i]); break;
     case 2: r = fexp<MODE>(a[i], tab); break;
+    case 3: r = div_03<MODE>(a[i]); break;
+    case 4: r = div_02<MODE>(a[i]); break;
     default: r = 0.0f;
     }
     out[i] = r;
@@ -1038,7 +1067,7 @@ __global__ void selftest_kernel(int op, const float* a, const float* b, float* o
 extern "C" int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mode, const float* a,
                                         const float* b, float* out, uint32_t n)
 {
-    if (!a || !out || (op == 0 && !b) || op < 0 || op > 2)
+    if (!a || !out || (op == 0 && !b) || op < 0 || op > 4)
         return fail(PEDONI_E_INVALID, "selftest: bad arguments");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)

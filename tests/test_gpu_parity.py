@@ -59,6 +59,21 @@ def test_device_div_sqrt_are_ieee(hip):
         assert bit_equal(abi.selftest_math(1, np.abs(a)), np.sqrt(np.abs(a))).all()
 
 
+def test_device_constant_division_is_ieee(hip):
+    """x / 0.3f and x / 0.2f by fma(x, zh, x*zl): exhaustively exact on the host for
+    2^-100 <= |x| <= 2^100; here the device form incl. its fallback range."""
+    from pedoni_amd import abi
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.uniform(-4, 4, 400000), rng.lognormal(0, 30, 100000),
+                        -rng.lognormal(0, 30, 100000), rng.integers(0, 2**32, 400000, dtype=np.uint64)
+                        .astype(np.uint32).view(np.float32),
+                        [0.0, -0.0, 1e-45, -1e-45, 7e-31, 8e-31, 1.2e30, 1.3e30, 3e38, np.inf, -np.inf,
+                         np.nan]]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        assert bit_equal(abi.selftest_math(3, x), x / np.float32(0.3)).all()
+        assert bit_equal(abi.selftest_math(4, x), x / np.float32(0.2)).all()
+
+
 def test_device_exp_replays_host_libm(hip):
     from pedoni_amd import abi
     rng = np.random.default_rng(2)
