@@ -125,6 +125,9 @@ def main() -> None:
                     help="skip the per-kernel hipEvent pairs in the timed region")
     args = ap.parse_args()
 
+    # RCCL prints a version banner on stdout: keep fd 1 for the ONE JSON line
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,8 +144,15 @@ def main() -> None:
         sys.exit("bench.py needs a HIP device: the backend has no CPU fallback")
     local_rank %= max(torch.cuda.device_count(), 1)   # (a rehearsal may share one card)
     torch.cuda.set_device(local_rank)
+    # PEDONI_FORCE_SHARDED=1: run the row-band path even with one rank (smoke test of the
+    # RCCL / stream plumbing on a single GPU); never set by the driver
+    force_sharded = os.environ.get("PEDONI_FORCE_SHARDED") == "1"
     dist = None
-    if world > 1:
+    if world > 1 or force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         # "nccl" IS RCCL on ROCm; PEDONI_DIST_BACKEND=gloo only rehearses the code path
         backend = os.environ.get("PEDONI_DIST_BACKEND", "nccl")
@@ -170,11 +180,12 @@ def main() -> None:
     model = abi.HipModel(opt, (width, height), field.distance_map, field.potential_maps,
                          field.unit, obstacles, device=local_rank)
 
-    if G > 1:
+    if G > 1 or force_sharded:
         from pedoni_amd.sharded import ShardedModel
         model.set_stream(stream.cuda_stream)
         runner = ShardedModel(model, rank, G, dist, torch,
-                              expected_row_agents=int(width * 1.4 * DENSITY))
+                              expected_row_agents=int(width * 1.4 * DENSITY),
+                              overlap=os.environ.get("PEDONI_OVERLAP") == "1")
         # this rank's agents: exactly its own band of grid rows (2 m clear of the outer walls)
         y_lo, y_hi = runner.lo * 1.4 + 0.01, runner.hi * 1.4 - 0.01
     else:
@@ -183,7 +194,7 @@ def main() -> None:
     pos, dest, v0, vel = uniform_crowd(
         n_per, (12.0, width - 12.0), (max(y_lo, 2.0), min(y_hi, height - 2.0)), seed=12345 + rank)
 
-    if G > 1:
+    if runner is not None:
         assert (runner.owner_of(pos[:, 1]) == rank).all()
         runner.load(pos, dest, v0, vel)
         step_fn = runner.tick_n
@@ -198,7 +209,8 @@ def main() -> None:
 
     step_fn(args.warmup)
     barrier()
-    n_before = model.owned_count() if G > 1 else model.get_pedestrian_count()
+    sharded = runner is not None
+    n_before = model.owned_count() if sharded else model.get_pedestrian_count()
     if not args.no_profile:
         # one hipEvent pair per step around the dominant kernel only (a pair around every
         # kernel costs ~40 us/step; the full breakdown is taken after the timed region)
@@ -211,7 +223,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     ktimes = model.kernel_times(reset=True) if not args.no_profile else {}
     model.profile(False)
-    n_after = model.owned_count() if G > 1 else model.get_pedestrian_count()
+    n_after = model.owned_count() if sharded else model.get_pedestrian_count()
     breakdown = {}
     if not args.no_profile:
         model.profile(True)
@@ -223,7 +235,7 @@ def main() -> None:
                      for k, v in bt.items() if v["launches"]}
 
     agents_local = 0.5 * (n_before + n_after)       # despawns during the run are negligible
-    if dist is not None:
+    if dist is not None and world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -242,7 +254,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "agents_total": int(round(agents_total)),
-                       "math_mode": args.math, "parallelism": f"row-bands x{G}" if G > 1 else "single GPU",
+                       "math_mode": args.math, "parallelism": f"row-bands x{G}" if sharded else "single GPU",
                        "field_build_s": round(t_field, 2),
                        "tick_algorithmic_GBps": BYTES_TICK * value / 1e9},
         }
@@ -262,7 +274,8 @@ def main() -> None:
         if G == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((width, height), field, obstacles, pos, dest, v0, vel,
                                                args.cpu_budget)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     model.close()
     if dist is not None:

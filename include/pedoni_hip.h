@@ -183,6 +183,12 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev,
  * update_states, then halo_pack of the NEXT tick's lists into `send_dev` */
 int pedoni_hip_halo_tick(PedoniModel* m, const void* from_below_dev, const void* from_above_dev,
                          void* send_dev, uint32_t cap_each);
+/* the same tick in two halves, so the all-gather of the next tick's lists overlaps the bulk
+ * of the force kernel: _begin = unpack, sort/despawn, update of the rows beside the band's
+ * edges, pack into `send_dev` (start the exchange now); _end = update of the interior rows */
+int pedoni_hip_halo_tick_begin(PedoniModel* m, const void* from_below_dev,
+                               const void* from_above_dev, void* send_dev, uint32_t cap_each);
+int pedoni_hip_halo_tick_end(PedoniModel* m);
 /* owned-agent count (excludes ghosts) */
 int pedoni_hip_owned_count(PedoniModel* m, int32_t* count);
 

@@ -36,6 +36,7 @@ SYMBOLS = [
     "pedoni_hip_synchronize", "pedoni_hip_profile", "pedoni_hip_kernel_times",
     "pedoni_hip_kernel_name", "pedoni_hip_set_band", "pedoni_hip_halo_bytes",
     "pedoni_hip_halo_pack", "pedoni_hip_halo_unpack", "pedoni_hip_halo_tick",
+    "pedoni_hip_halo_tick_begin", "pedoni_hip_halo_tick_end",
     "pedoni_hip_owned_count",
     "pedoni_hip_selftest_math",
 ]
@@ -347,6 +348,15 @@ class HipModel:
         _check(self._lib, self._lib.pedoni_hip_halo_tick(
             self._h, C.c_void_p(below_dev_ptr), C.c_void_p(above_dev_ptr),
             C.c_void_p(send_dev_ptr), C.c_uint32(cap_each)))
+
+    def halo_tick_begin(self, below_dev_ptr: Optional[int], above_dev_ptr: Optional[int],
+                        send_dev_ptr: int, cap_each: int) -> None:
+        _check(self._lib, self._lib.pedoni_hip_halo_tick_begin(
+            self._h, C.c_void_p(below_dev_ptr), C.c_void_p(above_dev_ptr),
+            C.c_void_p(send_dev_ptr), C.c_uint32(cap_each)))
+
+    def halo_tick_end(self) -> None:
+        _check(self._lib, self._lib.pedoni_hip_halo_tick_end(self._h))
 
     def owned_count(self) -> int:
         c = C.c_int32(0)

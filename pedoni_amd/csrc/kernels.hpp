@@ -411,15 +411,29 @@ __global__ void write_kernel(const uint32_t* __restrict__ key, const uint32_t* _
 // sfm.rs:66-75: an agent's place inside its cell is the number of cell-mates with a smaller
 // previous index; the slot list gives those indices in arbitrary (atomic arrival) order.
 __global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
-                               GridView grid, BandView band, const uint32_t* __restrict__ cs_new,
+                               GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
+                               const uint32_t* __restrict__ cs_new,
                                const uint32_t* __restrict__ slots,
                                const SortFlags* __restrict__ flags, uint32_t parity, SoA a)
 {
     // launched with a small fixed grid: in the common tick (gather form everywhere) every
     // wave leaves after one flag read
-    if (flags->far[parity] == 0 && !band.sharded) return;
-    for (uint32_t i = i0 + blockIdx.x * blockDim.x + threadIdx.x; i < n_total;
-         i += gridDim.x * blockDim.x) {
+    const bool everything = flags->far[parity] != 0;
+    if (!everything && !band.sharded) return;
+    // sharded, no far mover: only agents landing in the four boundary rows are in general
+    // form, and those come from the received lists or from own old rows <= lo+1 / >= hi-2:
+    // two index ranges [i0, skip_begin) and [skip_end, n_total)
+    uint32_t skip_begin = n_total, skip_end = n_total;
+    if (!everything && band.hi - band.lo >= 6) {
+        skip_begin = cs_old[(int64_t)(band.lo + 2) * grid.cols];
+        skip_end = cs_old[(int64_t)(band.hi - 2) * grid.cols];
+        if (skip_end < skip_begin) skip_end = skip_begin;
+    }
+    const uint32_t skipped = skip_end - skip_begin;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_total - i0 - skipped;
+         t += gridDim.x * blockDim.x) {
+        uint32_t i = i0 + t;
+        if (i >= skip_begin) i += skipped;
         uint32_t k = key[i];
         if (k == DEAD) continue;
         uint32_t cy = k / (uint32_t)grid.cols, cx = k - cy * (uint32_t)grid.cols;
@@ -465,6 +479,11 @@ struct ForceArgs {
     FieldView field;
     GridView grid;
     int32_t band_lo, band_hi; // rows whose agents are integrated (others are ghosts)
+    // agents handled by this launch: up to two runs of whole grid rows [seg_row[k][0],
+    // seg_row[k][1]) (index ranges read off cell_start); seg_row[0][0] < 0 = every sorted agent
+    int32_t seg_row[2][2];
+    int32_t clear_stale;   // segment launch: surplus threads write DEAD keys to stale slots
+    uint32_t* error_word;  // HaloIn.error: bit 2 = a segment was longer than its launch
     int32_t use_grid, use_distance_map;
     // fused K_KEY of the next sort/despawn pass (null = not requested): the agent's next
     // cell key (or DEAD) and the far-mover flag of the next tick's parity
@@ -639,8 +658,25 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     float4* queue = queue_all[wave];
     unsigned char* owner_of = owner_all[wave];
     float2* e_lds = e_all[wave];
-    const uint32_t id = a.base + blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n = *a.live_count;
+    uint32_t id = a.base + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = *a.live_count;
+    if (a.seg_row[0][0] >= 0) {                    // row-segment launch (sharded overlap)
+        uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t b0 = a.cell_start[(int64_t)a.seg_row[0][0] * a.grid.cols];
+        uint32_t e0 = a.cell_start[(int64_t)a.seg_row[0][1] * a.grid.cols];
+        uint32_t b1 = a.cell_start[(int64_t)a.seg_row[1][0] * a.grid.cols];
+        uint32_t e1 = a.cell_start[(int64_t)a.seg_row[1][1] * a.grid.cols];
+        if (t < e0 - b0) { id = b0 + t; n = e0; }
+        else { id = b1 + (t - (e0 - b0)); n = e1; }
+        uint32_t need = (e0 - b0) + (e1 - b1);
+        if (t == 0 && need > gridDim.x * blockDim.x) atomicOr(a.error_word, 4u);
+        if (t >= need) {
+            // surplus thread: clear the key of a slot left behind by a despawned agent
+            uint32_t stale = *a.live_count + (t - need);
+            if (a.clear_stale && a.key_next && stale < a.key_end) a.key_next[stale] = DEAD;
+            id = 0xffffffffu; n = 0;
+        }
+    }
     bool valid = id < n;
 
     v2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), acc = mk(0.0f, 0.0f), e = mk(0.0f, 0.0f);
@@ -763,7 +799,8 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     }
 
     if (!valid) {
-        if (a.key_next && id < a.key_end) a.key_next[id] = DEAD;  // slot of a despawned agent
+        // slot of a despawned agent (whole-array launches only: segments end at live agents)
+        if (a.key_next && a.seg_row[0][0] < 0 && id < a.key_end) a.key_next[id] = DEAD;
         return;
     }
     if (ghost) {                                                  // ghost row: never integrated

@@ -77,6 +77,8 @@ struct EventPair {
 struct PedoniModel {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t side_stream = nullptr;      // interior rows of a split sharded tick
+    hipEvent_t ev_sorted = nullptr, ev_interior = nullptr;
     PedoniOptions opt{};
     float size_x = 0, size_y = 0;
     Rng rng{12345};
@@ -137,6 +139,7 @@ struct PedoniModel {
     uint32_t n_upper = 0; // host upper bound of the end of stored agents
     uint32_t gap_end = 0;
     bool sorted = false;  // cell_start matches the current pos buffer
+    bool split_pending = false; // halo_tick_begin ran, halo_tick_end has not
     bool force_simple = false; // PEDONI_FORCE_SIMPLE=1: one-lane-per-agent force kernel
     int ablate = 0;            // PEDONI_ABLATE bitmask: timing diagnostics only, results wrong
     bool sort_general = false; // PEDONI_SORT_GENERAL=1: always take the atomic (general) sort form
@@ -179,7 +182,7 @@ struct Timed {
     int rc = PEDONI_OK;
     Timed(PedoniModel* m_, int kernel) : m(m_)
     {
-        if (!((m->profile_mask >> kernel) & 1u)) return;
+        if (kernel < 0 || !((m->profile_mask >> kernel) & 1u)) return;
         if (m->ev_used == m->ev_pool.size()) {
             if (m->ev_pool.size() >= 8192) {
                 rc = drain_events(m);
@@ -372,8 +375,8 @@ int sort_despawn(PedoniModel* m)
             Timed t(m, PEDONI_K_REORDER);
             if (t.rc) return t.rc;
             hipLaunchKernelGGL(reorder_kernel, dim3(std::min(blocks_for(n_threads, bs), 1024u)), dim3(bs), 0,
-                               m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_new],
-                               m->d_slots, m->d_flags, parity, soa);
+                               m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
+                               m->d_cs[cs_new], m->d_slots, m->d_flags, parity, soa);
         }
         m->cs = cs_new;
         m->sk = sk_new;
@@ -433,6 +436,9 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
     a.use_grid = m->opt.use_neighbor_grid;
     a.use_distance_map = m->opt.use_distance_map;
     a.ablate = m->ablate;
+    a.seg_row[0][0] = -1; a.seg_row[0][1] = a.seg_row[1][0] = a.seg_row[1][1] = 0;
+    a.clear_stale = 0;
+    a.error_word = &m->d_halo->error;
     // fuse the next pass's K_KEY when this launch integrates (queue kernel, grid mode)
     const bool fuse = !acc_out && m->opt.use_neighbor_grid && !m->force_simple && !m->no_fuse_key &&
                       m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
@@ -443,26 +449,54 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
     return a;
 }
 
-int launch_force(PedoniModel* m, float2* acc_out)
+// part: 0 = every sorted agent; 1 = the rows next to the band's edges (ghost rows, which
+// are only NaN-marked, and the two owned rows beside each); 2 = the interior rows.  Parts 1
+// and 2 together equal part 0; they exist so that a sharded tick can pack and send its
+// boundary agents while the interior is still being computed.
+int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on = nullptr)
 {
+    hipStream_t stream = on ? on : m->stream;
     uint32_t n = m->n_upper - m->base;
     if (n == 0) return PEDONI_OK;
     uint32_t bs = m->opt.gpu_work_size > 0 ? (uint32_t)m->opt.gpu_work_size : 256u;
     ForceArgs a = force_args(m, acc_out);
-    Timed t(m, PEDONI_K_FORCE);
+    if (part != 0) {
+        const int32_t rows = m->grid.rows;
+        const int32_t lo_a = std::max(m->band_lo - 1, 0), lo_b = std::min(m->band_lo + 2, m->band_hi);
+        const int32_t hi_a = std::max(m->band_hi - 2, lo_b), hi_b = std::min(m->band_hi + 1, rows);
+        if (part == 1) {
+            a.seg_row[0][0] = lo_a; a.seg_row[0][1] = lo_b;
+            a.seg_row[1][0] = hi_a; a.seg_row[1][1] = hi_b;
+            n = std::min(n, 8u * std::max(m->halo_cap, 1u)); // 6 rows, each <= ~0.7 halo_cap
+        } else {
+            a.seg_row[0][0] = lo_b; a.seg_row[0][1] = hi_a;
+            a.seg_row[1][0] = a.seg_row[1][1] = hi_a;
+            a.clear_stale = 1;
+        }
+    }
+    Timed t(m, on ? -1 : PEDONI_K_FORCE);   // the side-stream launch is not event-timed
     if (t.rc) return t.rc;
     const bool fast = m->opt.math_mode == PEDONI_MATH_FAST;
     if (m->opt.use_neighbor_grid && !m->force_simple) {
         dim3 grid(blocks_for(n, FORCE_THREADS)), block(FORCE_THREADS);
-        if (fast) hipLaunchKernelGGL((force_kernel_queue<1, 8>), grid, block, 0, m->stream, a);
-        else hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, m->stream, a);
+        if (fast) hipLaunchKernelGGL((force_kernel_queue<1, 8>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, stream, a);
     } else {
+        if (part != 0) return fail(PEDONI_E_INVALID, "row-segment force launch needs the queue kernel");
         dim3 grid(blocks_for(n, bs)), block(bs);
-        if (fast) hipLaunchKernelGGL(force_kernel_simple<1>, grid, block, 0, m->stream, a);
-        else hipLaunchKernelGGL(force_kernel_simple<0>, grid, block, 0, m->stream, a);
+        if (fast) hipLaunchKernelGGL(force_kernel_simple<1>, grid, block, 0, stream, a);
+        else hipLaunchKernelGGL(force_kernel_simple<0>, grid, block, 0, stream, a);
     }
     HIP_TRY(hipGetLastError());
     return PEDONI_OK;
+}
+
+void after_update(PedoniModel* m)
+{
+    if (m->n_upper > m->base) m->pv = 1 - m->pv;
+    m->keys_valid = m->n_upper > m->base && m->opt.use_neighbor_grid && !m->force_simple &&
+                    !m->no_fuse_key && m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
+    m->sorted = false;
 }
 
 // sfm.rs:91-255 on the device
@@ -473,10 +507,7 @@ int update_states(PedoniModel* m)
                     "update_states needs the sort/despawn pass of spawn_pedestrians first "
                     "(Simulator::tick order, lib.rs:85,90)");
     TRY(launch_force(m, nullptr));
-    if (m->n_upper > m->base) m->pv = 1 - m->pv;
-    m->keys_valid = m->n_upper > m->base && m->opt.use_neighbor_grid && !m->force_simple &&
-                    !m->no_fuse_key && m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
-    m->sorted = false;
+    after_update(m);
     return PEDONI_OK;
 }
 
@@ -605,6 +636,9 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
 
     C_HIP(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
     m->stream = m->own_stream;
+    C_HIP(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+    C_HIP(hipEventCreateWithFlags(&m->ev_sorted, hipEventDisableTiming));
+    C_HIP(hipEventCreateWithFlags(&m->ev_interior, hipEventDisableTiming));
 
     // field maps
     size_t texels = (size_t)field_rows * field_cols;
@@ -692,6 +726,9 @@ void pedoni_hip_destroy(PedoniModel* m)
     for (float* p : m->d_pot) hipFree(p);
     hipFree((void*)m->d_pot_ptrs);
     hipFree(m->d_obstacles);
+    if (m->side_stream) { hipStreamSynchronize(m->side_stream); hipStreamDestroy(m->side_stream); }
+    if (m->ev_sorted) hipEventDestroy(m->ev_sorted);
+    if (m->ev_interior) hipEventDestroy(m->ev_interior);
     if (m->own_stream) hipStreamDestroy(m->own_stream);
     delete m;
 }
@@ -962,6 +999,22 @@ int pedoni_hip_halo_bytes(uint32_t cap_each, uint64_t* bytes)
     return PEDONI_OK;
 }
 
+namespace {
+// `updated` = read positions / velocities from the buffer update_states is writing (the
+// boundary rows of a split tick are already there; the buffers flip when the tick ends)
+int halo_pack_from(PedoniModel* m, void* send_dev, uint32_t cap_each, bool updated)
+{
+    const int src = updated ? 1 - m->pv : m->pv;
+    Timed t(m, PEDONI_K_HALO_PACK);
+    if (t.rc) return t.rc;
+    hipLaunchKernelGGL(halo_pack_kernel, dim3(2), dim3(1024), 0, m->stream, m->d_pos[src],
+                       m->d_vel[src], m->d_v0[m->vd], m->d_dest[m->vd], m->d_cs[m->cs], m->grid,
+                       m->band_lo, m->band_hi, cap_each, (uint32_t*)send_dev);
+    HIP_TRY(hipGetLastError());
+    return PEDONI_OK;
+}
+} // namespace
+
 int pedoni_hip_halo_pack(PedoniModel* m, void* send_dev, uint32_t cap_each)
 {
     TRY(bind(m));
@@ -970,13 +1023,7 @@ int pedoni_hip_halo_pack(PedoniModel* m, void* send_dev, uint32_t cap_each)
         return fail(PEDONI_E_INVALID, "halo_pack: cap_each differs from set_band's halo capacity");
     if (!m->have_old)
         return fail(PEDONI_E_INVALID, "halo_pack: needs a sorted order (run sort_despawn once after loading)");
-    Timed t(m, PEDONI_K_HALO_PACK);
-    if (t.rc) return t.rc;
-    hipLaunchKernelGGL(halo_pack_kernel, dim3(2), dim3(1024), 0, m->stream, m->d_pos[m->pv],
-                       m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_cs[m->cs], m->grid,
-                       m->band_lo, m->band_hi, cap_each, (uint32_t*)send_dev);
-    HIP_TRY(hipGetLastError());
-    return PEDONI_OK;
+    return halo_pack_from(m, send_dev, cap_each, /*updated=*/false);
 }
 
 int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const void* from_above_dev,
@@ -1018,6 +1065,46 @@ int pedoni_hip_halo_tick(PedoniModel* m, const void* from_below_dev, const void*
     return pedoni_hip_halo_pack(m, send_dev, cap_each);
 }
 
+// The same tick in two halves, so that the exchange of the NEXT tick's lists overlaps the
+// bulk of this tick's force kernel:
+//   begin: unpack, sort/despawn, force + integrate the rows next to the band's edges, pack
+//          (the caller now starts the all-gather of `send_dev`, asynchronously)
+//   end:   force + integrate the interior rows
+int pedoni_hip_halo_tick_begin(PedoniModel* m, const void* from_below_dev, const void* from_above_dev,
+                               void* send_dev, uint32_t cap_each)
+{
+    TRY(pedoni_hip_halo_unpack(m, from_below_dev, from_above_dev, cap_each));
+    TRY(sort_despawn(m));
+    if (!send_dev) return fail(PEDONI_E_INVALID, "halo_tick_begin: null send buffer");
+    if (m->band_hi - m->band_lo < 6 || m->force_simple) {
+        // band too thin to split: whole tick now, nothing left for _end
+        TRY(update_states(m));
+        m->split_pending = false;
+        return halo_pack_from(m, send_dev, cap_each, false);
+    }
+    // interior rows on the side stream, concurrently with the (small, latency-bound) edge-row
+    // launch, the pack and the exchange the caller starts next
+    // (edge rows are enqueued first so that their few blocks are dispatched ahead of the
+    // interior's thousands)
+    HIP_TRY(hipEventRecord(m->ev_sorted, m->stream));
+    TRY(launch_force(m, nullptr, /*part=*/1));
+    HIP_TRY(hipStreamWaitEvent(m->side_stream, m->ev_sorted, 0));
+    TRY(launch_force(m, nullptr, /*part=*/2, m->side_stream));
+    HIP_TRY(hipEventRecord(m->ev_interior, m->side_stream));
+    m->split_pending = true;
+    return halo_pack_from(m, send_dev, cap_each, /*updated=*/true);
+}
+
+int pedoni_hip_halo_tick_end(PedoniModel* m)
+{
+    TRY(bind(m));
+    if (!m->split_pending) return PEDONI_OK;
+    HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_interior, 0)); // join before the next pass
+    after_update(m);
+    m->split_pending = false;
+    return PEDONI_OK;
+}
+
 int pedoni_hip_owned_count(PedoniModel* m, int32_t* count)
 {
     TRY(bind(m));
@@ -1035,6 +1122,8 @@ int pedoni_hip_owned_count(PedoniModel* m, int32_t* count)
     if (h.error & 1u) return fail(PEDONI_E_CAPACITY, "halo list overflow: raise the halo capacity");
     if (h.error & 2u)
         return fail(PEDONI_E_INVALID, "an agent left its band by more than one grid row in one tick");
+    if (h.error & 4u)
+        return fail(PEDONI_E_CAPACITY, "boundary rows hold more agents than 8 x halo capacity: raise it");
     *count = (int32_t)(hi - lo);
     return PEDONI_OK;
 }
