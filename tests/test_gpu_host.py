@@ -45,6 +45,70 @@ def test_simulator_narrow_gap_matches_oracle(hip, oracle):
     sim.close()
 
 
+def test_simulator_periodic_spawns_match_oracle_replica(hip, oracle):
+    """Simulator::tick with periodic spawners (lib.rs:67-85): count = poisson(frequency / 10),
+    pos = lerp(origin line, f32()) from the seeded stream, then spawn_pedestrians (append +
+    sort/despawn: the general sort form runs on every tick that spawns) and update_states.
+    The replica drives the oracle with the same streams; positions must match bit for bit."""
+    from pedoni_amd import host
+    text = """
+[field]
+size = [60, 40]
+[[waypoints]]
+line = [[5, 5], [5, 35]]
+[[waypoints]]
+line = [[55, 5], [55, 35]]
+[[obstacles]]
+line = [[30, 0], [30, 15]]
+width = 1
+[[obstacles]]
+line = [[30, 40], [30, 22]]
+width = 1.5
+[[pedestrians]]
+origin = 0
+destination = 1
+spawn = { kind = "periodic", frequency = 40.0 }
+[[pedestrians]]
+origin = 1
+destination = 0
+spawn = { kind = "periodic", frequency = 25.0 }
+[[pedestrians]]
+origin = 0
+destination = 1
+spawn = { kind = "once", count = 7 }
+"""
+    seed = 99
+    sim = host.Simulator(host.SimulatorOptions(seed=seed), host.Scenario(text))
+    sc = scn.loads(text)
+    field = oracle_field(oracle, sc)
+    rng = oracle.Rng(seed)
+    cpu = oracle.OracleModel(sc.field.size, seed=seed ^ 0x5eed)
+
+    def lerp_line(w, u):
+        p1, p2 = (np.array(p, np.float32) for p in sc.waypoints[w].line)
+        return p1 * (np.float32(1) - u) + p2 * u
+
+    new = [lerp_line(0, np.float32(rng.f32())) for _ in range(7)]            # lib.rs:37-52
+    cpu.spawn_pedestrians(field, np.array(new, np.float32), np.ones(7, np.uint32))
+    for t in range(120):
+        m = sim.tick()
+        pos, dest = [], []
+        for p in sc.pedestrians:                                              # lib.rs:70-84
+            if isinstance(p.spawn, scn.SpawnPeriodic):
+                for _ in range(rng.poisson(p.spawn.frequency / 10.0)):
+                    pos.append(lerp_line(p.origin, np.float32(rng.f32())))
+                    dest.append(p.destination)
+        cpu.spawn_pedestrians(field, np.array(pos, np.float32).reshape(-1, 2), np.array(dest, np.uint32))
+        cpu.update_states(field)
+        wp, wd, _, _ = cpu.download()
+        got = sim.list_pedestrians()
+        assert m["active_ped_count"] == len(wp) == len(got), f"tick {t}"
+        assert np.array_equal(got["destination"], wd), f"tick {t}"
+        assert bit_equal(np.stack([got["x"], got["y"]], 1), wp).all(), f"tick {t}"
+    assert len(got) > 300
+    sim.close()
+
+
 def test_simulator_periodic_spawns_grow_the_crowd(hip):
     from pedoni_amd import host
     text = """
