@@ -50,7 +50,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
 def build_host(force: bool = False, verbose: bool = False) -> Path | None:
     """C++ host mirror of pedoni-simulator's Simulator (links against libpedoni_hip)."""
     host_dir = CSRC / "host"
-    srcs = sorted(host_dir.glob("*.cpp"))
+    srcs = sorted(p for p in host_dir.glob("*.cpp") if not p.name.endswith("_main.cpp"))
     if not srcs:
         return None
     out = LIBDIR / "libpedoni_host.so"
@@ -61,6 +61,26 @@ def build_host(force: bool = False, verbose: bool = False) -> Path | None:
            "-fno-fast-math", "-Wall", "-Wextra", "-pthread", f"-I{INCLUDE}", f"-I{host_dir}",
            "-o", str(out), *map(str, srcs), f"-L{LIBDIR}", "-lpedoni_hip",
            "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return out
+
+
+def build_cli(force: bool = False, verbose: bool = False) -> Path | None:
+    """pedoni-headless: the reference binary's headless mode on the C++ host mirror."""
+    src = CSRC / "host" / "headless_main.cpp"
+    if not src.exists():
+        return None
+    bindir = ROOT / "pedoni_amd" / "bin"
+    bindir.mkdir(parents=True, exist_ok=True)
+    out = bindir / "pedoni-headless"
+    deps = [src, CSRC / "host" / "pedoni_host.hpp", LIBDIR / "libpedoni_host.so"]
+    if not force and _newer(out, deps):
+        return out
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-Wall", "-Wextra", "-pthread", f"-I{INCLUDE}",
+           f"-I{CSRC / 'host'}", "-o", str(out), str(src), f"-L{LIBDIR}", "-lpedoni_host",
+           "-lpedoni_hip", "-Wl,-rpath,$ORIGIN/../lib"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
@@ -80,6 +100,7 @@ def build_oracle(force: bool = False) -> Path:
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_hip(force, verbose)
     build_host(force, verbose)
+    build_cli(force, verbose)
     build_oracle(force)
 
 

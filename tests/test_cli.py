@@ -1,0 +1,48 @@
+"""pedoni-headless: the reference binary's headless mode (pedoni/src/main.rs:106-136,
+args.rs) on the C++ host mirror."""
+import json
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+BIN = ROOT / "pedoni_amd" / "bin" / "pedoni-headless"
+SCENARIO = ROOT / "tests" / "golden" / "scenarios" / "narrow_gap.toml"
+
+
+def run(*args, **kw):
+    return subprocess.run([str(BIN), *map(str, args)], capture_output=True, text=True, timeout=300, **kw)
+
+
+def test_cli_usage_and_argument_errors():
+    assert BIN.exists(), "build with `python -m pedoni_amd.build`"
+    r = run("--help")
+    assert r.returncode == 0 and "--max-steps" in r.stdout and "--no-neighbor-grid" in r.stdout
+    r = run(SCENARIO)                       # the renderer is out of scope
+    assert r.returncode != 0 and "headless" in r.stderr
+    r = run("-H", "-b", "opencl", SCENARIO)
+    assert r.returncode != 0 and "possible values" in r.stderr
+    r = run("-H", "--bogus", SCENARIO)
+    assert r.returncode != 0 and "unexpected argument" in r.stderr
+    r = run("-H", "does/not/exist.toml")
+    assert r.returncode != 0 and "cannot read" in r.stderr
+    r = run("-H", "-b", "cpu", SCENARIO)    # the reference's own models are not substituted
+    assert r.returncode != 0 and "not part of this build" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_headless_run_writes_the_diagnostic_log(tmp_path):
+    r = run("-H", "-s", "1000000", "--max-steps", "120", "--log-dir", tmp_path, "--seed", "3", SCENARIO)
+    assert r.returncode == 0, r.stderr
+    assert "Step:    100, Active pedestrians:" in r.stderr          # main.rs:87-92
+    logs = list(tmp_path.glob("*_log.json"))
+    assert len(logs) == 1
+    d = json.loads(logs[0].read_text())
+    assert set(d) == {"model", "scenario", "total_steps", "preprocess_metrics", "step_metrics"}
+    assert d["total_steps"] == 121                                   # stops once total_steps > max_steps
+    sm = d["step_metrics"]
+    assert set(sm) == {"active_ped_count", "time_spawn", "time_calc_state", "time_calc_state_kernel"}
+    assert all(len(v) == 121 for v in sm.values())
+    assert sm["active_ped_count"][0] == 50 and sm["time_calc_state_kernel"][0] is None
+    assert d["preprocess_metrics"]["time_calc_field"] > 0
