@@ -680,7 +680,6 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     bool valid = id < n;
 
     v2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), acc = mk(0.0f, 0.0f), e = mk(0.0f, 0.0f);
-    v2 wall = mk(0.0f, 0.0f);
     float2 vv = make_float2(0.0f, 0.0f);
     float desired_speed = 0.0f;
     uint32_t r0 = 0, r1 = 0, r2 = 0, n0 = 0, n1 = 0, n2 = 0;
@@ -699,10 +698,6 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
             if (a.ablate & 1) e = mk(1.0f, 0.0f);
             else e = goal_direction<MODE>(a.field, pos, destination); // :107-108
             acc = acc + vdiv<MODE>(e * desired_speed - vel, 0.5f); // :109
-            // the wall term only needs the agent's own position: sample the distance map
-            // now, so its texel loads overlap the potential map's; it is ADDED after the
-            // pair forces, where the reference adds it (:188-192)
-            if (a.use_distance_map && !(a.ablate & 2)) wall = obstacle_force_map<MODE>(a.field, pos, tab);
             int32_t y_start = max(iy - 1, 0), y_end = min(iy + 1, a.grid.rows - 1); // :117-118
             int32_t x_start = max(ix - 1, 0), x_end = min(ix + 1, a.grid.cols - 1); // :119-120
             // rows y_start..y_end in ascending order; a missing row contributes nothing
@@ -814,7 +809,7 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     }
 
     if (a.ablate & 2) {}
-    else if (a.use_distance_map) acc = acc + wall;
+    else if (a.use_distance_map) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
     else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
 
     if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); return; }

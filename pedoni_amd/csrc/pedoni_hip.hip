@@ -1153,6 +1153,7 @@ __global__ void selftest_kernel(int op, const float* a, const float* b, float* o
     case 2: r = fexp<MODE>(a[i], tab); break;
     case 3: r = div_03<MODE>(a[i]); break;
     case 4: r = div_02<MODE>(a[i]); break;
+    case 5: r = __int_as_float(f32_as_i32(a[i])); break;   // raw i32 bits
     default: r = 0.0f;
     }
     out[i] = r;
@@ -1162,7 +1163,7 @@ __global__ void selftest_kernel(int op, const float* a, const float* b, float* o
 extern "C" int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mode, const float* a,
                                         const float* b, float* out, uint32_t n)
 {
-    if (!a || !out || (op == 0 && !b) || op < 0 || op > 4)
+    if (!a || !out || (op == 0 && !b) || op < 0 || op > 5)
         return fail(PEDONI_E_INVALID, "selftest: bad arguments");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
