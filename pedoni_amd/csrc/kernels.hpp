@@ -644,6 +644,11 @@ __global__ void force_kernel_simple(ForceArgs a)
 // Tuning notes (N = 1e6, exact mode): 6 slots per batch = 28 KB LDS per block = 5 waves/SIMD
 // at 82 VGPR: 0.141 ms; 8 slots (4 waves) 0.151; 12-16 slots (3-2 waves) 0.22; forcing 6
 // waves (<= 80 VGPR, 12 B spill) 0.141: the kernel sits on a ~80 % VALU-busy plateau.
+// Carrying the < 64 left-over queue entries of a batch into the next one (full phase-2
+// rounds only, -20 % rounds) was built, verified bit-exact and measured: 0.142 ms, no gain
+// -- a partly filled round is cheap (idle half-waves are skipped) and the carry bookkeeping
+// costs what it saves.  Ablation of the final kernel: pairs ~95 us, field stencils ~22 us,
+// loads / fused key / integrator / stores ~28 us.
 constexpr int FORCE_THREADS = 256;
 constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 
