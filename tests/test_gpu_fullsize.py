@@ -84,3 +84,29 @@ def test_c4_bottleneck_x5_1e6(hip, oracle, use_distance_map):
     vel[:, 0] = np.where(dest == 1, 0.5, -0.5) * v0
     _run_case(hip, oracle, sc.field.size, field, sc.obstacle_array(), pos, dest, v0, vel, ticks=2,
               use_distance_map=use_distance_map)
+
+
+def test_soak_600_ticks_100k_agents(hip, oracle):
+    """Long free run: 600 ticks of 100 000 agents with no host read-back in between, then a
+    bitwise comparison with the oracle's own 600 ticks.  (Chaos is no obstacle when every
+    tick is bit-identical.)  Agents reach their goals and despawn along the way."""
+    from helpers import inject_crowd, oracle_field, random_obstacle_scenario
+    sc = random_obstacle_scenario(260.0, 400, seed=3)
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 100_000, 4, seed=5)
+    cpu = oracle.OracleModel(sc.field.size)
+    gpu = hip.HipModel(hip.Options(), sc.field.size, field.distance_map, field.potential_maps,
+                       field.unit, sc.obstacle_array())
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    for chunk in (200, 400):
+        gpu.tick_n(chunk)
+        for _ in range(chunk):
+            cpu.spawn_pedestrians(field)
+            cpu.update_states(field)
+        gp, gd, gv, g0 = gpu.download()
+        wp, wd, wv, w0 = cpu.download()
+        assert len(gp) == len(wp) and np.array_equal(gd, wd)
+        assert bit_equal(gp, wp).all() and bit_equal(gv, wv).all() and bit_equal(g0, w0).all()
+    assert len(gp) < 100_000          # some agents arrived and despawned
+    gpu.close()

@@ -23,7 +23,7 @@ def _tall_box(width, height):
     return sc
 
 
-@pytest.mark.parametrize("world,n", [(2, 20_000), (3, 50_000), (5, 8_000)])
+@pytest.mark.parametrize("world,n", [(2, 20_000), (3, 50_000), (5, 8_000), (8, 120_000)])
 def test_bands_reproduce_single_gpu_bitwise(hip, oracle, world, n):
     import torch
     from pedoni_amd.sharded import ShardedModel
