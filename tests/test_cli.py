@@ -46,3 +46,32 @@ def test_cli_headless_run_writes_the_diagnostic_log(tmp_path):
     assert all(len(v) == 121 for v in sm.values())
     assert sm["active_ped_count"][0] == 50 and sm["time_calc_state_kernel"][0] is None
     assert d["preprocess_metrics"]["time_calc_field"] > 0
+
+
+def _build_c_demo(tmp_path):
+    exe = tmp_path / "c_abi_demo"
+    lib = ROOT / "pedoni_amd" / "lib"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", f"-I{ROOT / 'include'}",
+                    str(ROOT / "examples" / "c_abi_demo.c"), f"-L{lib}", "-lpedoni_host", "-lpedoni_hip",
+                    f"-Wl,-rpath,{lib}", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_c_abi_headers_compile_as_plain_c(tmp_path):
+    """include/*.h are C, not C++: the demo builds with gcc -std=c11 -Werror and, without a
+    GPU, fails at pedoni_hip_create with the library's error string (no CPU fallback)."""
+    exe = _build_c_demo(tmp_path)
+    from pedoni_amd import abi
+    if abi.device_count() == 0:
+        r = subprocess.run([str(exe), str(SCENARIO), "3"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "pedoni_hip_create" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_abi_demo_runs_the_trait_calls(tmp_path):
+    exe = _build_c_demo(tmp_path)
+    r = subprocess.run([str(exe), str(SCENARIO), "150"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("ticks=150 active=")
+    active = int(r.stdout.split("active=")[1].split()[0])
+    assert 0 <= active <= 20
