@@ -20,6 +20,19 @@ using PedoniObstacleDev = ::PedoniObstacle;
 
 constexpr uint32_t DEAD = 0xffffffffu;
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  Agents are sorted
+// by cell, so neighbouring workgroups share most of their candidate lines: map the hardware
+// block id so that every XCD works through ONE contiguous eighth of the agents (its blocks
+// b, b+8, b+16 ... become logical blocks k, k+1, k+2 ...) and neighbour rows are served by
+// the same L2.  Bijective for any grid size (cdna_hip_programming.md T1); placement is a
+// speed matter only.
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t n_blocks)
+{
+    const uint32_t q = n_blocks / 8u, r = n_blocks % 8u, xcd = b % 8u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
+}
+
+
 struct GridView {
     float unit;
     int32_t rows, cols; // NeighborGrid.shape = (rows, cols) (neighbor_grid.rs:14-20)
@@ -157,7 +170,7 @@ __global__ void count_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
                              const SortFlags* __restrict__ flags, uint32_t parity,
                              uint32_t* __restrict__ cell_count, uint32_t* __restrict__ rank)
 {
-    uint32_t j = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t j = i0 + xcd_contiguous_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     // the NEXT tick's flag is raised by this tick's update_states and the next K_KEY; it can
     // be cleared here because K_KEY of this tick has finished and nothing reads it now
     if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<SortFlags*>(flags)->far[parity ^ 1u] = 0;
@@ -394,7 +407,7 @@ __global__ void write_kernel(const uint32_t* __restrict__ key, const uint32_t* _
                              const SortFlags* __restrict__ flags, uint32_t parity, SoA a,
                              uint32_t* __restrict__ slots)
 {
-    uint32_t j = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t j = i0 + xcd_contiguous_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (j >= n_total) return;
     uint32_t c = key[j];
     if (c == DEAD) return;
@@ -491,6 +504,7 @@ struct ForceArgs {
     uint32_t key_end;    // stale slots [live, key_end) get DEAD keys
     SortFlags* flags;
     uint32_t parity_next;
+    int32_t xcd_remap; // XCD-contiguous block order (PEDONI_NO_XCD_REMAP=1 turns it off)
     int32_t ablate; // diagnostics only (PEDONI_ABLATE): 1 = no goal sampling, 2 = no obstacle term, 4 = no pairs
 };
 
@@ -666,10 +680,11 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     float4* queue = queue_all[wave];
     unsigned char* owner_of = owner_all[wave];
     float2* e_lds = e_all[wave];
-    uint32_t id = a.base + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    uint32_t id = a.base + block * blockDim.x + threadIdx.x;
     uint32_t n = *a.live_count;
     if (a.seg_row[0][0] >= 0) {                    // row-segment launch (sharded overlap)
-        uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t t = block * blockDim.x + threadIdx.x;
         uint32_t b0 = a.cell_start[(int64_t)a.seg_row[0][0] * a.grid.cols];
         uint32_t e0 = a.cell_start[(int64_t)a.seg_row[0][1] * a.grid.cols];
         uint32_t b1 = a.cell_start[(int64_t)a.seg_row[1][0] * a.grid.cols];

@@ -144,6 +144,7 @@ struct PedoniModel {
     int ablate = 0;            // PEDONI_ABLATE bitmask: timing diagnostics only, results wrong
     bool sort_general = false; // PEDONI_SORT_GENERAL=1: always take the atomic (general) sort form
     bool no_fuse_key = false;  // PEDONI_NO_FUSE_KEY=1: standalone K_KEY every tick
+    bool xcd_remap = true;     // PEDONI_NO_XCD_REMAP=1: hardware block order
     int force_slots = 6;       // PEDONI_FORCE_SLOTS: candidates per lane per batch (6 or 8)
 
     // profiling
@@ -437,6 +438,7 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
     a.use_grid = m->opt.use_neighbor_grid;
     a.use_distance_map = m->opt.use_distance_map;
     a.ablate = m->ablate;
+    a.xcd_remap = m->xcd_remap ? 1 : 0;
     a.seg_row[0][0] = -1; a.seg_row[0][1] = a.seg_row[1][0] = a.seg_row[1][1] = 0;
     a.clear_stale = 0;
     a.error_word = &m->d_halo->error;
@@ -629,6 +631,8 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
         m->sort_general = sg && sg[0] == '1';
         const char* nf = std::getenv("PEDONI_NO_FUSE_KEY");
         m->no_fuse_key = nf && nf[0] == '1';
+        const char* nx = std::getenv("PEDONI_NO_XCD_REMAP");
+        m->xcd_remap = !(nx && nx[0] == '1');
         const char* fsl = std::getenv("PEDONI_FORCE_SLOTS");
         if (fsl) m->force_slots = std::atoi(fsl);
         const char* s3 = std::getenv("PEDONI_SCAN3");
