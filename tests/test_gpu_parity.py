@@ -347,6 +347,92 @@ def test_far_movers_and_spawns_switch_to_general_form(hip, oracle):
     gpu.close()
 
 
+def test_capacity_growth_mid_run_keeps_order_and_state(hip, oracle):
+    """The SoA arrays double when a spawn does not fit (all device pointers change); the
+    sorted order, the keys and the stale-slot bookkeeping must survive it."""
+    sc = box_scenario(120.0)
+    field = oracle_field(oracle, sc)
+    rng = np.random.default_rng(31)
+    cpu = oracle.OracleModel(sc.field.size, seed=9)
+    gpu = _make_hip(hip, sc, field, seed=9, initial_capacity=1)      # 1024-agent minimum
+    total = 0
+    for step in range(14):
+        n_new = int(rng.integers(200, 900))
+        new = rng.uniform(15, 105, (n_new, 2)).astype(np.float32)
+        nd = rng.integers(0, 2, n_new).astype(np.uint32)
+        cpu.spawn_pedestrians(field, new, nd)
+        gpu.spawn_pedestrians(new, nd)
+        total += n_new
+        assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices()), step
+        if step % 3 == 2:
+            gpu.tick_n(2)
+            for _ in range(2):
+                cpu.update_states(field)
+                cpu.spawn_pedestrians(field)
+            gpu.sort_despawn()
+        else:
+            cpu.update_states(field)
+            gpu.update_states()
+        _assert_state_equal(gpu.download(), cpu.download(), f"step {step}")
+    assert total > 4096                                               # several doublings happened
+    gpu.close()
+
+
+def test_dense_crowd_six_per_square_metre(hip, oracle):
+    """rho = 6 / m^2 (a crush): ~100 candidates and ~75 in-range pairs per agent, many
+    batches per wave in the force kernel, ~12 agents per cell in the sort."""
+    sc = box_scenario(70.0)
+    field = oracle_field(oracle, sc)
+    n = 6 * 60 * 60
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, n, 2, seed=17, clearance=1.0)
+    pos = (5.0 + (pos - 0.6) * (60.0 / 68.8)).astype(np.float32)      # squeeze into 60 m x 60 m
+    cpu = oracle.OracleModel(sc.field.size)
+    gpu = _make_hip(hip, sc, field)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    for step in range(4):
+        cpu.update_states(field)
+        gpu.update_states()
+        _assert_state_equal(gpu.download(), cpu.download(), f"step {step} integrated")
+        cpu.spawn_pedestrians(field)
+        gpu.spawn_pedestrians()
+        assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices())
+    gpu.close()
+
+
+@pytest.mark.parametrize("work_size", [64, 128, 1024])
+def test_gpu_work_size_option(hip, oracle, work_size):
+    """SimulatorOptions.gpu_work_size (lib.rs:121,132): workgroup size of the one-lane-per-
+    agent force kernel (brute-force path); results do not depend on it."""
+    sc = random_obstacle_scenario(50.0, 20)
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 900, 4, seed=work_size)
+    cpu = oracle.OracleModel(sc.field.size, use_neighbor_grid=False)
+    gpu = _make_hip(hip, sc, field, use_neighbor_grid=False, gpu_work_size=work_size)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    cpu.update_states(field)
+    gpu.update_states()
+    _assert_state_equal(gpu.download(), cpu.download(), "integrated")
+    gpu.close()
+
+
+def test_invalid_options_are_rejected(hip, oracle):
+    from pedoni_amd import abi
+    sc = box_scenario(30.0)
+    field = oracle_field(oracle, sc)
+    with pytest.raises(abi.PedoniError, match="multiple of 64"):
+        _make_hip(hip, sc, field, gpu_work_size=100)
+    with pytest.raises(abi.PedoniError, match="neighbor_grid_unit"):
+        _make_hip(hip, sc, field, neighbor_grid_unit=0.0)
+    gpu = _make_hip(hip, sc, field)
+    with pytest.raises(abi.PedoniError, match="sort/despawn pass"):
+        gpu.update_states()                       # Simulator::tick order: spawn first (lib.rs:85,90)
+    gpu.close()
+
+
 # ---- option paths ------------------------------------------------------------------------
 def test_no_neighbor_grid_bruteforce_path(hip, oracle):
     """use_neighbor_grid = false: filter-only despawn (sfm.rs:78-88), O(N^2) pairs (:157-185)."""
