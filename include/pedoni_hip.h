@@ -141,6 +141,21 @@ int pedoni_hip_neighbor_grid_shape(PedoniModel* m, uint32_t* rows, uint32_t* col
 /* [ext] accelerations of sfm.rs:93-241 for the current sorted state (no integration) */
 int pedoni_hip_calc_accelerations(PedoniModel* m, float* acc_xy, uint32_t cap);
 
+/* [ext] on-device periodic spawning.  Installs the scenario's
+ * `periodic` spawners (lib.rs:70-84): from then on every tick of pedoni_hip_tick_n first
+ * draws, on the device, count = poisson(frequency / 10) arrivals per spawner at
+ * p1.lerp(p2, u) from the POSITION stream (continued from `position_rng_state`, the host
+ * Simulator's generator state) and their desired speeds from the model's own stream --
+ * draw for draw what Simulator::tick + spawn_pedestrians do on the host, so both routes give
+ * bit-identical crowds.  `max_per_tick` bounds one tick's arrivals (exceeding it is reported
+ * as PEDONI_E_CAPACITY by owned_count / get_spawn_rng callers; no silent drop).  n == 0
+ * uninstalls.  Not available for a band of a sharded run. */
+typedef struct { float x0, y0, x1, y1; uint32_t destination; uint32_t reserved; double frequency; } PedoniSpawner;
+int pedoni_hip_set_spawners(PedoniModel* m, const PedoniSpawner* spawners, uint32_t n,
+                            uint64_t position_rng_state, uint32_t max_per_tick);
+/* current states of the two streams (to hand spawning back to the host) */
+int pedoni_hip_get_spawn_rng(PedoniModel* m, uint64_t* position_rng_state, uint64_t* speed_rng_state);
+
 /* [ext] stream / timing */
 /* All launches and copies of the model go to `hip_stream` (a hipStream_t; NULL is HIP's
  * default stream) or, with use_library_stream != 0, back to the model's own stream. */

@@ -86,6 +86,9 @@ int pedoni_simulator_new(const PedoniSimulatorOptions* opt, const PedoniScenario
 void pedoni_simulator_free(PedoniSimulator* sim);
 /* Simulator::tick (lib.rs:64-100) */
 int pedoni_simulator_tick(PedoniSimulator* sim, PedoniStepMetrics* metrics);
+/* build-owned: `n` ticks with the periodic spawners evaluated on the device (bit-identical
+ * crowd to n calls of pedoni_simulator_tick, no per-tick host work); metrics of the batch */
+int pedoni_simulator_tick_n(PedoniSimulator* sim, uint32_t n, PedoniStepMetrics* metrics);
 /* pub field `step` (lib.rs:22) */
 int pedoni_simulator_step(const PedoniSimulator* sim, int32_t* step);
 /* Simulator::list_pedestrians (lib.rs:102-104) */

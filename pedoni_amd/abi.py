@@ -38,7 +38,7 @@ SYMBOLS = [
     "pedoni_hip_halo_pack", "pedoni_hip_halo_unpack", "pedoni_hip_halo_tick",
     "pedoni_hip_halo_tick_begin", "pedoni_hip_halo_tick_end",
     "pedoni_hip_owned_count",
-    "pedoni_hip_selftest_math",
+    "pedoni_hip_selftest_math", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng",
 ]
 
 

@@ -216,6 +216,21 @@ int pedoni_simulator_tick(PedoniSimulator* sim, PedoniStepMetrics* m)
     });
 }
 
+int pedoni_simulator_tick_n(PedoniSimulator* sim, uint32_t n, PedoniStepMetrics* m)
+{
+    if (!sim) return fail(PEDONI_E_INVALID, "null simulator");
+    return guarded([&] {
+        StepMetrics sm = sim->sim->tick_n(n);
+        if (m) {
+            m->active_ped_count = sm.active_ped_count;
+            m->time_spawn = sm.time_spawn;
+            m->time_calc_state = sm.time_calc_state;
+            m->time_calc_state_kernel = sm.time_calc_state_kernel.value_or(-1.0);
+        }
+        return PEDONI_OK;
+    });
+}
+
 int pedoni_simulator_step(const PedoniSimulator* sim, int32_t* step)
 {
     if (!sim || !step) return fail(PEDONI_E_INVALID, "null argument");

@@ -157,10 +157,17 @@ public:
 
     Simulator(SimulatorOptions options, Scenario scenario); // lib.rs:27-61
     StepMetrics tick();                                     // lib.rs:64-100
+    // build-owned: `n` ticks with the periodic spawners evaluated ON THE DEVICE (same two RNG
+    // streams, so the crowd is bit-identical to n calls of tick()); no per-tick host work.
+    // The returned metrics cover the whole batch.
+    StepMetrics tick_n(uint32_t n);
     std::vector<Pedestrian> list_pedestrians() const { return model->list_pedestrians(); } // :102
 
 private:
     Rng rng_;
+    bool device_spawners_ = false;
+    void hand_spawning_to_device();
+    void take_spawning_back();
 };
 
 } // namespace pedoni_host

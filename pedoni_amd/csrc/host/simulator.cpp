@@ -146,9 +146,57 @@ Simulator::Simulator(SimulatorOptions options_, Scenario scenario_)
     model->spawn_pedestrians(field, std::move(new_pedestrians));           // lib.rs:52
 }
 
+void Simulator::hand_spawning_to_device()
+{
+    auto* hip = dynamic_cast<SocialForceModelHip*>(model.get());
+    if (!hip) throw std::runtime_error("Simulator::tick_n needs the Hip backend");
+    std::vector<PedoniSpawner> sp;
+    double per_tick = 0.0;
+    for (const PedestrianConfig& p : scenario.pedestrians) {                // lib.rs:70-72, same order
+        if (p.spawn.kind != PedestrianSpawnConfig::Periodic) continue;
+        const Vec2 p1 = scenario.waypoints[p.origin].line[0], p2 = scenario.waypoints[p.origin].line[1];
+        sp.push_back(PedoniSpawner{p1.x, p1.y, p2.x, p2.y, (uint32_t)p.destination, 0u, p.spawn.frequency});
+        per_tick += p.spawn.frequency / 10.0;
+    }
+    // Poisson mean + 12 sigma + slack: exceeding it is reported, never silently dropped
+    const uint32_t cap = (uint32_t)(per_tick + 12.0 * std::sqrt(per_tick + 1.0) + 64.0);
+    check(pedoni_hip_set_spawners(hip->handle(), sp.data(), (uint32_t)sp.size(), rng_.state, cap),
+          "Simulator::tick_n");
+    device_spawners_ = !sp.empty();
+}
+
+void Simulator::take_spawning_back()
+{
+    auto* hip = dynamic_cast<SocialForceModelHip*>(model.get());
+    if (!hip || !device_spawners_) return;
+    uint64_t pos_state = rng_.state;
+    check(pedoni_hip_get_spawn_rng(hip->handle(), &pos_state, nullptr), "Simulator::tick");
+    rng_.state = pos_state;
+    check(pedoni_hip_set_spawners(hip->handle(), nullptr, 0, 0, 0), "Simulator::tick");
+    device_spawners_ = false;
+}
+
+StepMetrics Simulator::tick_n(uint32_t n)
+{
+    using clk = std::chrono::steady_clock;
+    auto* hip = dynamic_cast<SocialForceModelHip*>(model.get());
+    if (!hip) throw std::runtime_error("Simulator::tick_n needs the Hip backend");
+    if (!device_spawners_) hand_spawning_to_device();
+    const auto t0 = clk::now();
+    check(pedoni_hip_tick_n(hip->handle(), n), "Simulator::tick_n");
+    check(pedoni_hip_synchronize(hip->handle()), "Simulator::tick_n");
+    step += (int32_t)n;
+    StepMetrics m;
+    m.active_ped_count = model->get_pedestrian_count();
+    m.time_spawn = 0.0;
+    m.time_calc_state = std::chrono::duration<double>(clk::now() - t0).count();
+    return m;
+}
+
 StepMetrics Simulator::tick()
 {
     using clk = std::chrono::steady_clock;
+    take_spawning_back();   // (a previous tick_n left the spawn streams on the device)
     step += 1;                                                              // lib.rs:65
 
     auto instant = clk::now();                                              // lib.rs:68

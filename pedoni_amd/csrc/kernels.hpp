@@ -83,9 +83,14 @@ __device__ __forceinline__ uint32_t pack_cell(uint32_t cx, uint32_t cy) { return
 // One thread per stored agent.  Slots [live, gap_end) hold agents despawned by earlier
 // ticks (the host only knows an upper bound of the live count) and are skipped.
 struct HaloIn {
+    // the first three words describe agents stored by the device since the last pass and are
+    // cleared by the pass that consumes them
     uint32_t n_below; // agents received from the band below: stored at [base - n_below, base)
-    uint32_t n_above; // agents received from the band above: stored at [gap_end, gap_end + n_above)
-    uint32_t error;   // sticky: bit 0 = a sender overflowed its list, bit 1 = an agent left its band by > 1 row
+    uint32_t n_above; // agents received from the band above / spawned on the device: stored at
+                      // [gap_end, gap_end + n_above)
+    uint32_t counted; // 1: the appended range's length is n_above (not the host's bound)
+    uint32_t error;   // sticky: bit 0 = a sender overflowed its list, bit 1 = an agent left its band
+                      // by > 1 row, bit 2 = edge rows exceed their launch, bit 3 = spawn overflow
     uint32_t sharded; // 1 once the model exchanges halos
 };
 
@@ -103,7 +108,7 @@ __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __res
     if (i >= n_total) return;
     uint32_t live = *live_count;
     uint32_t n_below = halo->n_below;
-    uint32_t app_end = halo->sharded ? gap_end + halo->n_above : n_total;
+    uint32_t app_end = (halo->sharded || halo->counted) ? gap_end + halo->n_above : n_total;
     bool own = i >= base && i < live;
     bool received = (i < base && i >= base - n_below) || (i >= gap_end && i < app_end);
     uint32_t k = DEAD;
@@ -866,6 +871,70 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
         }
         a.key_next[id] = k;
     }
+}
+
+// ---- on-device periodic spawning (Simulator::tick, lib.rs:67-85 + sfm.rs:49-56) ---------------
+// One thread replays, draw for draw, what the host does each tick: per periodic spawner
+// count = poisson(frequency / 10) (util.rs:78-89, Knuth's product of f64 uniforms) and
+// pos = p1.lerp(p2, f32()) from the position stream, then one desired speed per new agent
+// from the model's own stream (Irwin-Hall(12), the build-owned generator).  A few dozen
+// agents per tick: the serial kernel costs microseconds and removes the last per-tick host
+// touch, so whole tick_n batches of a spawning scenario run without the host.
+struct SpawnerDev {
+    float x0, y0, x1, y1;
+    uint32_t destination, pad;
+    double exp_neg_lambda; // exp(-frequency / 10), computed by the host's libm as upstream does
+};
+struct SpawnState { unsigned long long rng_pos, rng_v0; };
+
+__device__ __forceinline__ unsigned long long wyrand_next(unsigned long long& s)
+{
+    s += 0xa0761d6478bd642fULL;
+    unsigned long long b = s ^ 0xe7037ed1a0b428dbULL;
+    return __umul64hi(s, b) ^ (s * b);
+}
+__device__ __forceinline__ float wyrand_f32(unsigned long long& s) { return (float)(wyrand_next(s) >> 40) * 0x1.0p-24f; }
+__device__ __forceinline__ double wyrand_f64(unsigned long long& s) { return (double)(wyrand_next(s) >> 11) * 0x1.0p-53; }
+
+__global__ void spawn_kernel(const SpawnerDev* __restrict__ sp, uint32_t n_sp, SpawnState* __restrict__ st,
+                             uint32_t at0, uint32_t cap, float2* __restrict__ pos,
+                             float2* __restrict__ vel, float* __restrict__ v0,
+                             uint32_t* __restrict__ dest, HaloIn* __restrict__ halo)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned long long rp = st->rng_pos, rv = st->rng_v0;
+    uint32_t n = 0, dropped = 0;
+    for (uint32_t k = 0; k < n_sp; ++k) {
+        int32_t count = 0;                                    // util.rs:78-89
+        double x = wyrand_f64(rp);
+        while (x >= sp[k].exp_neg_lambda) {
+            x *= wyrand_f64(rp);
+            count += 1;
+        }
+        for (int32_t c = 0; c < count; ++c) {                 // lib.rs:75-81
+            float u = wyrand_f32(rp);
+            float w = 1.0f - u;                               // glam lerp: a * (1 - s) + b * s
+            float2 p = make_float2(sp[k].x0 * w + sp[k].x1 * u, sp[k].y0 * w + sp[k].y1 * u);
+            if (n < cap) {
+                pos[at0 + n] = p;
+                vel[at0 + n] = make_float2(0.0f, 0.0f);       // sfm.rs:53
+                dest[at0 + n] = sp[k].destination;
+                n += 1;
+            } else {
+                dropped += 1;
+            }
+        }
+    }
+    for (uint32_t i = 0; i < n + dropped; ++i) {              // sfm.rs:54, one draw per agent
+        float acc = 0.0f;
+        for (int j = 0; j < 12; ++j) acc += wyrand_f32(rv);
+        if (i < n) v0[at0 + i] = 1.34f + 0.26f * (acc - 6.0f);
+    }
+    st->rng_pos = rp;
+    st->rng_v0 = rv;
+    halo->n_above = n;
+    halo->counted = 1;
+    if (dropped) atomicOr(&halo->error, 8u);
 }
 
 // ---- halo exchange (no reference counterpart) -------------------------------

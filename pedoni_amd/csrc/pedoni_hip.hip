@@ -136,6 +136,10 @@ struct PedoniModel {
     uint32_t base = 0;
     uint32_t halo_cap = 0;
     HaloIn* d_halo = nullptr;
+    // on-device periodic spawning
+    SpawnerDev* d_spawners = nullptr;
+    SpawnState* d_spawn_state = nullptr;
+    uint32_t n_spawners = 0, spawn_cap = 0;
     uint32_t n_upper = 0; // host upper bound of the end of stored agents
     uint32_t gap_end = 0;
     bool sorted = false;  // cell_start matches the current pos buffer
@@ -410,8 +414,8 @@ int sort_despawn(PedoniModel* m)
     m->pv = dst;
     m->vd = vdst;
     m->gap_end = m->n_upper; // every stored agent is now either live (< *d_live) or stale
-    if (m->halo_cap) // the received lists are consumed: nothing in front of base any more
-        HIP_TRY(hipMemsetAsync(m->d_halo, 0, 2 * sizeof(uint32_t), m->stream));
+    if (m->halo_cap || m->n_spawners) // the device-stored agents are consumed
+        HIP_TRY(hipMemsetAsync(m->d_halo, 0, 3 * sizeof(uint32_t), m->stream));
     m->sorted = true;
     return PEDONI_OK;
 }
@@ -523,6 +527,11 @@ int sync_live_count(PedoniModel* m, uint32_t* out)
                            m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     uint32_t live = m->h_pinned[0]; // absolute end index
+    if (m->n_spawners) { // a tick that spawned more than max_per_tick must not pass silently
+        HaloIn h{};
+        HIP_TRY(hipMemcpy(&h, m->d_halo, sizeof h, hipMemcpyDeviceToHost));
+        if (h.error & 8u) return fail(PEDONI_E_CAPACITY, "a tick spawned more agents than max_per_tick");
+    }
     // tighten the host bound when nothing has been appended since the last pass
     if (m->gap_end == m->n_upper) m->n_upper = m->gap_end = live;
     *out = live - m->base;
@@ -538,8 +547,22 @@ int append(PedoniModel* m, const float* pos_xy, const uint32_t* destination,
         return fail(PEDONI_E_INVALID, "append: too many agents");
     TRY(ensure_capacity(m, m->n_upper + n));
     std::vector<float> v0(n);
-    if (desired_speed) std::memcpy(v0.data(), desired_speed, n * sizeof(float));
-    else for (uint32_t i = 0; i < n; ++i) v0[i] = m->rng.normal_approx(1.34f, 0.26f); // sfm.rs:54
+    if (desired_speed) {
+        std::memcpy(v0.data(), desired_speed, n * sizeof(float));
+    } else {
+        SpawnState st{};
+        if (m->n_spawners) { // the desired-speed stream lives on the device: continue it
+            HIP_TRY(hipMemcpyAsync(&st, m->d_spawn_state, sizeof st, hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            m->rng.s = st.rng_v0;
+        }
+        for (uint32_t i = 0; i < n; ++i) v0[i] = m->rng.normal_approx(1.34f, 0.26f); // sfm.rs:54
+        if (m->n_spawners) {
+            st.rng_v0 = m->rng.s;
+            HIP_TRY(hipMemcpyAsync(m->d_spawn_state, &st, sizeof st, hipMemcpyHostToDevice, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+        }
+    }
     size_t at = m->n_upper;
     HIP_TRY(hipMemcpyAsync(m->d_pos[m->pv] + at, pos_xy, n * sizeof(float2), hipMemcpyHostToDevice,
                            m->stream));
@@ -730,6 +753,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     hipFree(m->d_scan_in); hipFree(m->d_cs[0]); hipFree(m->d_cs[1]); hipFree(m->d_block_sums);
     hipFree(m->d_skey[0]); hipFree(m->d_skey[1]); hipFree(m->d_flags);
     hipFree(m->d_live); hipFree(m->d_acc); hipFree(m->d_halo);
+    hipFree(m->d_spawners); hipFree(m->d_spawn_state);
     hipFree(m->d_scan_words); hipFree(m->d_scan_ticket);
     if (m->h_pinned) hipHostFree(m->h_pinned);
     hipFree(m->d_distance_map);
@@ -780,13 +804,85 @@ int pedoni_hip_update_states(PedoniModel* m)
     return update_states(m);
 }
 
+namespace {
+// lib.rs:70-84 + sfm.rs:49-56 on the device: append this tick's Poisson arrivals
+int device_spawn(PedoniModel* m)
+{
+    if (m->gap_end != m->n_upper)
+        return fail(PEDONI_E_INVALID, "device spawning: host-appended agents are pending; run a pass first");
+    if ((uint64_t)m->n_upper + m->spawn_cap > m->cap) { // tighten the host bound before growing
+        uint32_t live = 0;
+        TRY(sync_live_count(m, &live));
+    }
+    TRY(ensure_capacity(m, m->n_upper + m->spawn_cap));
+    Timed t(m, PEDONI_K_OTHER);
+    if (t.rc) return t.rc;
+    hipLaunchKernelGGL(spawn_kernel, dim3(1), dim3(64), 0, m->stream, m->d_spawners, m->n_spawners,
+                       m->d_spawn_state, m->n_upper, m->spawn_cap, m->d_pos[m->pv], m->d_vel[m->pv],
+                       m->d_v0[m->vd], m->d_dest[m->vd], m->d_halo);
+    HIP_TRY(hipGetLastError());
+    m->gap_end = m->n_upper;        // the spawned agents start here
+    m->n_upper += m->spawn_cap;     // host bound; the device knows the true count
+    m->sorted = false;
+    return PEDONI_OK;
+}
+} // namespace
+
 int pedoni_hip_tick_n(PedoniModel* m, uint32_t steps)
 {
     TRY(bind(m));
     for (uint32_t s = 0; s < steps; ++s) {
+        if (m->n_spawners) TRY(device_spawn(m));
         TRY(sort_despawn(m));
         TRY(update_states(m));
     }
+    return PEDONI_OK;
+}
+
+int pedoni_hip_set_spawners(PedoniModel* m, const PedoniSpawner* spawners, uint32_t n,
+                            uint64_t position_rng_state, uint32_t max_per_tick)
+{
+    TRY(bind(m));
+    if (n && !spawners) return fail(PEDONI_E_INVALID, "set_spawners: null spawners");
+    if (m->halo_cap) return fail(PEDONI_E_INVALID, "set_spawners: not supported for a band of a sharded run");
+    if (n && max_per_tick == 0) return fail(PEDONI_E_INVALID, "set_spawners: max_per_tick must be > 0");
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->n_spawners) { // hand the desired-speed stream back to the host side
+        SpawnState st{};
+        HIP_TRY(hipMemcpy(&st, m->d_spawn_state, sizeof st, hipMemcpyDeviceToHost));
+        m->rng.s = st.rng_v0;
+    }
+    hipFree(m->d_spawners);
+    m->d_spawners = nullptr;
+    m->n_spawners = 0;
+    m->spawn_cap = 0;
+    if (n == 0) return PEDONI_OK;
+    std::vector<SpawnerDev> dev(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        if (!(spawners[k].frequency >= 0.0)) return fail(PEDONI_E_INVALID, "set_spawners: bad frequency");
+        dev[k] = SpawnerDev{spawners[k].x0, spawners[k].y0, spawners[k].x1, spawners[k].y1,
+                            spawners[k].destination, 0u, std::exp(-(spawners[k].frequency / 10.0))};
+    }
+    TRY(dev_alloc(&m->d_spawners, n));
+    HIP_TRY(hipMemcpy(m->d_spawners, dev.data(), n * sizeof(SpawnerDev), hipMemcpyHostToDevice));
+    if (!m->d_spawn_state) TRY(dev_alloc(&m->d_spawn_state, 1));
+    SpawnState st{position_rng_state, m->rng.s};
+    HIP_TRY(hipMemcpy(m->d_spawn_state, &st, sizeof st, hipMemcpyHostToDevice));
+    m->n_spawners = n;
+    m->spawn_cap = max_per_tick;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_get_spawn_rng(PedoniModel* m, uint64_t* position_rng_state, uint64_t* speed_rng_state)
+{
+    TRY(bind(m));
+    SpawnState st{0, m->rng.s};
+    if (m->n_spawners) {
+        HIP_TRY(hipMemcpyAsync(&st, m->d_spawn_state, sizeof st, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    if (position_rng_state) *position_rng_state = st.rng_pos;
+    if (speed_rng_state) *speed_rng_state = st.rng_v0;
     return PEDONI_OK;
 }
 
@@ -829,8 +925,10 @@ int pedoni_hip_get_pedestrian_count(PedoniModel* m, int32_t* count)
     if (!count) return fail(PEDONI_E_INVALID, "null count");
     uint32_t live = 0;
     TRY(sync_live_count(m, &live));
-    // agents appended since the last pass are part of `self.pedestrians` upstream too
-    *count = (int32_t)(live + (m->n_upper - m->gap_end));
+    // agents appended by the host since the last pass are part of `self.pedestrians` upstream
+    // too (device-stored ranges are bounds, not counts: they are consumed by the next pass)
+    const bool device_ranges = m->halo_cap || m->n_spawners;
+    *count = (int32_t)(live + (device_ranges ? 0u : m->n_upper - m->gap_end));
     return PEDONI_OK;
 }
 
@@ -1134,6 +1232,8 @@ int pedoni_hip_owned_count(PedoniModel* m, int32_t* count)
         return fail(PEDONI_E_INVALID, "an agent left its band by more than one grid row in one tick");
     if (h.error & 4u)
         return fail(PEDONI_E_CAPACITY, "boundary rows hold more agents than 8 x halo capacity: raise it");
+    if (h.error & 8u)
+        return fail(PEDONI_E_CAPACITY, "a tick spawned more agents than max_per_tick");
     *count = (int32_t)(hi - lo);
     return PEDONI_OK;
 }

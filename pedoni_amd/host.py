@@ -23,7 +23,7 @@ SYMBOLS = [
     "pedoni_field_free", "pedoni_field_shape", "pedoni_field_distance_map",
     "pedoni_field_potential_map", "pedoni_field_obstacle_exist", "pedoni_field_get_potential",
     "pedoni_field_get_obstacle_distance", "pedoni_simulator_new", "pedoni_simulator_free",
-    "pedoni_simulator_tick", "pedoni_simulator_step", "pedoni_simulator_list_pedestrians",
+    "pedoni_simulator_tick", "pedoni_simulator_tick_n", "pedoni_simulator_step", "pedoni_simulator_list_pedestrians",
     "pedoni_simulator_model", "pedoni_simulator_field",
 ]
 
@@ -248,6 +248,13 @@ class Simulator:
         return {"active_ped_count": m.active_ped_count, "time_spawn": m.time_spawn,
                 "time_calc_state": m.time_calc_state,
                 "time_calc_state_kernel": None if k < 0 else k}
+
+    def tick_n(self, n: int) -> dict:
+        """`n` ticks with the periodic spawners evaluated on the device."""
+        m = abi._StepMetrics()
+        _check(self._lib.pedoni_simulator_tick_n(self._h, C.c_uint32(n), C.byref(m)))
+        return {"active_ped_count": m.active_ped_count, "time_spawn": m.time_spawn,
+                "time_calc_state": m.time_calc_state, "time_calc_state_kernel": None}
 
     @property
     def step(self) -> int:
