@@ -62,7 +62,53 @@ def uniform_crowd(n: int, x_range, y_range, seed: int):
     return pos, dest, v0, vel
 
 
-def cpu_baseline(size, field, obstacles, pos, dest, v0, vel, budget_s: float = 20.0):
+def free_space_crowd(field, size, n, n_dest, seed, dest_rule=None):
+    """Seeded crowd in free space (distance map > 0.6 m): v0 ~ N(1.34, 0.26) clipped, velocity
+    0.5 * v0 towards +x / -x by destination parity."""
+    rng = np.random.default_rng(seed)
+    dm = field.distance_map
+    pos = np.zeros((0, 2), np.float32)
+    while len(pos) < n:
+        p = rng.uniform([2.0, 2.0], [size[0] - 2.0, size[1] - 2.0], (int((n - len(pos)) * 1.3) + 1000, 2)
+                        ).astype(np.float32)
+        iy, ix = (p[:, 1] / field.unit).astype(int), (p[:, 0] / field.unit).astype(int)
+        pos = np.concatenate([pos, p[dm[iy, ix] > 0.6]])[:n]
+    dest = dest_rule(pos) if dest_rule else rng.integers(0, n_dest, n).astype(np.uint32)
+    v0 = np.clip(rng.normal(1.34, 0.26, n), 0.5, 2.2).astype(np.float32)
+    vel = np.zeros((n, 2), np.float32)
+    vel[:, 0] = np.where(dest % 2 == 1, 0.5, -0.5) * v0
+    return pos, dest.astype(np.uint32), v0, vel
+
+
+def other_workload(name):
+    """BASELINE.json configs[1] (C2) and configs[3] (C4) as optional bench workloads."""
+    if name == "c2":       # random.toml-style: 200 x 200 m, 4 corner waypoints, 1004 thin walls
+        L, rng = 200.0, np.random.default_rng(7)
+        a, b = 0.05 * L, 0.1 * L
+        waypoints = np.array([[a, b, b, a, 1], [L - a, b, L - b, a, 1], [a, L - b, b, L - a, 1],
+                              [L - a, L - b, L - b, L - a, 1]], np.float32)
+        walls = [[0, 0, 0, L, 0.2], [0, L, L, L, 0.2], [0, 0, L, 0, 0.2], [L, 0, L, L, 0.2]]
+        for _ in range(1000):
+            c, ang = rng.uniform(0.05 * L, 0.95 * L, 2), rng.uniform(0, np.pi)
+            d = np.array([np.cos(ang), np.sin(ang)]) * 2.5
+            walls.append([*(c - d), *(c + d), 0.2])
+        obstacles = np.array(walls, np.float32)
+        crowd = lambda field: free_space_crowd(field, (L, L), 100_000, 4, seed=100)
+        return obstacles, waypoints, (L, L), crowd, \
+            "random-obstacle field 200x200 m, 1004 walls, N=1e5 injected agents (rho~2.5/m^2), 4 destinations"
+    # bottleneck.toml geometry x5 (tests/golden/scenarios/bottleneck_x5.toml)
+    obstacles = np.array([[250, 0, 500, 450, 25], [250, 1000, 500, 550, 25], [750, 0, 500, 450, 25],
+                          [750, 1000, 500, 550, 25]], np.float32)
+    waypoints = np.array([[50, 50, 50, 950, 1], [950, 50, 950, 950, 1]], np.float32)
+    rule = lambda pos: (pos[:, 0] < 500.0).astype(np.uint32)   # counter-flow halves
+    crowd = lambda field: free_space_crowd(field, (1000.0, 1000.0), 1_000_000, 2, seed=4, dest_rule=rule)
+    path = "explicit wall segments" if name == "c4seg" else "distance map"
+    return obstacles, waypoints, (1000.0, 1000.0), crowd, \
+        f"bottleneck x5 (1000x1000 m, 4 funnel walls), N=1e6 counter-flow, obstacle force via {path}"
+
+
+def cpu_baseline(size, field, obstacles, pos, dest, v0, vel, budget_s: float = 20.0,
+                 use_distance_map: bool = True):
     """Time the CPU oracle (oracle/, C port of the reference's CPU path with its parallel
     structure: serial sort/despawn, parallel-for accelerations, serial integrator) on a
     bounded sample of the SAME workload.  Checker code, used here only as the baseline."""
@@ -74,7 +120,7 @@ def cpu_baseline(size, field, obstacles, pos, dest, v0, vel, budget_s: float = 2
         pass
     cores = min(cores, 32)   # a 1-GPU box's CPU share; the serial passes dominate anyway
     ofield = pyoracle.Field(field.unit, field.distance_map, field.potential_maps)
-    m = pyoracle.OracleModel(size, threads=cores)
+    m = pyoracle.OracleModel(size, threads=cores, use_distance_map=use_distance_map)
     m.spawn_pedestrians(ofield, pos, dest, v0, vel)
     steps, t_used = 0, 0.0
     t0 = time.perf_counter()
@@ -119,6 +165,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--agents-per-gpu", type=int, default=AGENTS_PER_GPU)
     ap.add_argument("--math", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--workload", choices=["c3", "c2", "c4", "c4seg"], default="c3",
+                    help="c3 = BASELINE metric workload (default, the only one the driver runs); "
+                         "c2 = random-obstacle field with 1e5 agents; c4 = bottleneck x5 with 1e6 "
+                         "agents (distance map); c4seg = same with explicit wall segments")
     ap.add_argument("--work-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -172,12 +222,20 @@ def main() -> None:
     workload = (f"uniform crowd N={n_per * G:.0e} ({n_per:.0e}/GPU) in a {width:.0f}x{height:.0f} m box, "
                 f"rho={DENSITY:g}/m^2, neighbor grid 1.4 m, field maps 0.25 m, fp32").replace("e+0", "e")
 
+    custom_crowd = None
+    if args.workload != "c3":
+        if G != 1:
+            sys.exit("--workload c2/c4 are single-GPU configurations")
+        obstacles, waypoints, (width, height), custom_crowd, workload = other_workload(args.workload)
+        n_per = 100_000 if args.workload == "c2" else 1_000_000
+
     t0 = time.perf_counter()
     field = host.Field.build((width, height), 0.25, obstacles, waypoints)
     t_field = time.perf_counter() - t0
 
     opt = abi.Options(math_mode=abi.MATH_FAST if args.math == "fast" else abi.MATH_EXACT,
-                      gpu_work_size=args.work_size, initial_capacity=int(n_per * 1.3))
+                      gpu_work_size=args.work_size, initial_capacity=int(n_per * 1.3),
+                      use_distance_map=args.workload != "c4seg")
     model = abi.HipModel(opt, (width, height), field.distance_map, field.potential_maps,
                          field.unit, obstacles, device=local_rank)
 
@@ -192,8 +250,11 @@ def main() -> None:
     else:
         runner = None
         y_lo, y_hi = 0.0, height
-    pos, dest, v0, vel = uniform_crowd(
-        n_per, (12.0, width - 12.0), (max(y_lo, 2.0), min(y_hi, height - 2.0)), seed=12345 + rank)
+    if custom_crowd is not None:
+        pos, dest, v0, vel = custom_crowd(field)
+    else:
+        pos, dest, v0, vel = uniform_crowd(
+            n_per, (12.0, width - 12.0), (max(y_lo, 2.0), min(y_hi, height - 2.0)), seed=12345 + rank)
 
     if runner is not None:
         assert (runner.owner_of(pos[:, 1]) == rank).all()
@@ -274,7 +335,7 @@ def main() -> None:
             out["roofline"] = None
         if G == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((width, height), field, obstacles, pos, dest, v0, vel,
-                                               args.cpu_budget)
+                                               args.cpu_budget, args.workload != "c4seg")
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
