@@ -1014,33 +1014,58 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
                                    const uint32_t* __restrict__ from_above, uint32_t cap_each,
                                    uint32_t base, uint32_t gap_end, float2* __restrict__ pos,
                                    float2* __restrict__ vel, float* __restrict__ v0,
-                                   uint32_t* __restrict__ dest, HaloIn* __restrict__ halo)
+                                   uint32_t* __restrict__ dest, HaloIn* __restrict__ halo,
+                                   FieldView field, GridView grid, int32_t band_lo, int32_t band_hi,
+                                   uint32_t parity, SortFlags* __restrict__ flags,
+                                   uint32_t* __restrict__ key)
 {
+    // thread t < cap: landing slot base - cap + t (the list is right-aligned against base);
+    // thread t >= cap: slot gap_end + (t - cap).  Every slot gets a key -- the record's cell
+    // (same arithmetic as key_kernel) or DEAD for an unused slot -- so the pass that follows
+    // needs no K_KEY launch for the exchanged agents.
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2u * cap_each) return;
     uint32_t n_below = from_below ? min(from_below[0], cap_each) : 0u;
     uint32_t n_above = from_above ? min(from_above[0], cap_each) : 0u;
     if (t == 0) {
         halo->n_below = n_below;
         halo->n_above = n_above;
+        halo->counted = 0;
         halo->sharded = 1;
         uint32_t err = (from_below ? from_below[1] : 0u) | (from_above ? from_above[1] : 0u);
         if (err) atomicOr(&halo->error, err);
     }
     const uint32_t* src = nullptr;
-    uint32_t at = 0;
-    if (t < n_below) {
-        src = from_below + PEDONI_HALO_HEADER_WORDS + (size_t)t * PEDONI_HALO_RECORD_WORDS;
-        at = base - n_below + t;
-    } else if (t >= cap_each && t - cap_each < n_above) {
+    uint32_t at;
+    if (t < cap_each) {
+        at = base - cap_each + t;
+        uint32_t unused = cap_each - n_below;
+        if (t >= unused) src = from_below + PEDONI_HALO_HEADER_WORDS + (size_t)(t - unused) * PEDONI_HALO_RECORD_WORDS;
+    } else {
         uint32_t k = t - cap_each;
-        src = from_above + PEDONI_HALO_HEADER_WORDS + (size_t)k * PEDONI_HALO_RECORD_WORDS;
         at = gap_end + k;
+        if (k < n_above) src = from_above + PEDONI_HALO_HEADER_WORDS + (size_t)k * PEDONI_HALO_RECORD_WORDS;
     }
-    if (!src) return;
-    pos[at] = make_float2(__uint_as_float(src[0]), __uint_as_float(src[1]));
-    vel[at] = make_float2(__uint_as_float(src[2]), __uint_as_float(src[3]));
-    v0[at] = __uint_as_float(src[4]);
-    dest[at] = src[5];
+    uint32_t kk = DEAD;
+    if (src) {
+        v2 p = mk(__uint_as_float(src[0]), __uint_as_float(src[1]));
+        uint32_t d = src[5];
+        pos[at] = make_float2(p.x, p.y);
+        vel[at] = make_float2(__uint_as_float(src[2]), __uint_as_float(src[3]));
+        v0[at] = __uint_as_float(src[4]);
+        dest[at] = d;
+        int64_t c = cell_of(grid, p);
+        if (c >= 0 && survives(field, p, d)) {
+            int32_t cy = (int32_t)(c / grid.cols);
+            if (cy >= band_lo - 1 && cy <= band_hi) {
+                kk = (uint32_t)c;
+                // exchanged agents belong in the four boundary rows (general sort form there);
+                // anywhere else the whole pass must take the general form
+                if (!(cy <= band_lo || cy >= band_hi - 1)) atomicOr(&flags->far[parity], 1u);
+            }
+        }
+    }
+    key[at] = kk;
 }
 
 } // namespace pedoni

@@ -144,6 +144,8 @@ struct PedoniModel {
     uint32_t gap_end = 0;
     bool sorted = false;  // cell_start matches the current pos buffer
     bool split_pending = false; // halo_tick_begin ran, halo_tick_end has not
+    uint32_t ticks_since_tighten = 0; // device-stored appends since the host last read the count
+    bool halo_keys_done = false; // halo_unpack_kernel keyed the exchanged agents of this pass
     bool force_simple = false; // PEDONI_FORCE_SIMPLE=1: one-lane-per-agent force kernel
     int ablate = 0;            // PEDONI_ABLATE bitmask: timing diagnostics only, results wrong
     bool sort_general = false; // PEDONI_SORT_GENERAL=1: always take the atomic (general) sort form
@@ -352,13 +354,13 @@ int sort_despawn(PedoniModel* m)
                                    m->d_skey[sk_old], force_general, parity, m->d_flags, m->d_key);
             } else {
                 // own agents got their keys from the last update_states; only agents stored
-                // since then (appended / exchanged lists) are keyed here
-                if (m->halo_cap)
+                // since then are keyed here (exchanged lists were keyed by halo_unpack_kernel)
+                if (m->halo_cap && !m->halo_keys_done)
                     hipLaunchKernelGGL(key_kernel, dim3(blocks_for(m->halo_cap, bs)), dim3(bs), 0,
                                        m->stream, m->d_pos[src], m->d_dest[vsrc], i0, m->base, m->base,
                                        m->d_live, m->gap_end, m->d_halo, m->field, m->grid, m->band_lo,
                                        m->band_hi, m->d_skey[sk_old], 0, parity, m->d_flags, m->d_key);
-                if (n_total > m->gap_end)
+                if (n_total > m->gap_end && !m->halo_keys_done)
                     hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_total - m->gap_end, bs)), dim3(bs),
                                        0, m->stream, m->d_pos[src], m->d_dest[vsrc], m->gap_end, n_total,
                                        m->base, m->d_live, m->gap_end, m->d_halo, m->field, m->grid,
@@ -389,6 +391,7 @@ int sort_despawn(PedoniModel* m)
         m->tick_parity += 1;
         m->have_old = true;
         m->keys_valid = false; // consumed
+        m->halo_keys_done = false;
     } else {
         {
             Timed t(m, PEDONI_K_BIN);
@@ -810,9 +813,11 @@ int device_spawn(PedoniModel* m)
 {
     if (m->gap_end != m->n_upper)
         return fail(PEDONI_E_INVALID, "device spawning: host-appended agents are pending; run a pass first");
-    if ((uint64_t)m->n_upper + m->spawn_cap > m->cap) { // tighten the host bound before growing
+    // same bound bookkeeping as halo_unpack: re-read the device's count every 16 ticks
+    if (++m->ticks_since_tighten >= 16 || (uint64_t)m->n_upper + m->spawn_cap > m->cap) {
         uint32_t live = 0;
         TRY(sync_live_count(m, &live));
+        m->ticks_since_tighten = 0;
     }
     TRY(ensure_capacity(m, m->n_upper + m->spawn_cap));
     Timed t(m, PEDONI_K_OTHER);
@@ -1140,11 +1145,16 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
     TRY(bind(m));
     if (cap_each != m->halo_cap || cap_each == 0)
         return fail(PEDONI_E_INVALID, "halo_unpack: cap_each differs from set_band's halo capacity");
-    // the list from above lands behind everything stored: make room, tightening the host
-    // bound of the live count first when the arrays are about to run out
-    if ((uint64_t)m->n_upper + cap_each > m->cap && m->gap_end == m->n_upper) {
+    // The list from above lands behind everything stored, so the host's bound of the end
+    // of the arrays grows by cap_each per tick although the true count (on the device) does
+    // not.  Re-read the count every 16 ticks -- one stream sync per 16 ticks, ~1.5 us per
+    // tick amortised -- so launches never cover more than ~7 % idle threads; and always
+    // before the arrays would have to grow.
+    if (m->gap_end == m->n_upper &&
+        (++m->ticks_since_tighten >= 16 || (uint64_t)m->n_upper + cap_each > m->cap)) {
         uint32_t live = 0;
         TRY(sync_live_count(m, &live));
+        m->ticks_since_tighten = 0;
     }
     TRY(ensure_capacity(m, m->n_upper + cap_each));
     const uint32_t words_each = PEDONI_HALO_HEADER_WORDS + cap_each * PEDONI_HALO_RECORD_WORDS;
@@ -1156,10 +1166,12 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
     if (t.rc) return t.rc;
     hipLaunchKernelGGL(halo_unpack_kernel, dim3(blocks_for(2 * cap_each, 256)), dim3(256), 0,
                        m->stream, below, above, cap_each, m->base, m->n_upper, m->d_pos[m->pv],
-                       m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_halo);
+                       m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_halo, m->field, m->grid,
+                       m->band_lo, m->band_hi, m->tick_parity & 1u, m->d_flags, m->d_key);
     HIP_TRY(hipGetLastError());
     m->gap_end = m->n_upper;      // the above list starts here
     m->n_upper += cap_each;       // host bound; the device knows the true count
+    m->halo_keys_done = true;     // the exchanged agents already carry their keys
     m->sorted = false;
     return PEDONI_OK;
 }
