@@ -6,9 +6,12 @@
 // Data layout in HBM (structure of arrays, all fp32 / u32):
 //   pos[2][cap] float2, vel[2][cap] float2      ping-pong twice per tick (sort, integrate)
 //   desired_speed[2][cap] f32, destination[2][cap] u32   ping-pong once per tick (sort)
-//   key[cap] u32 (cell id or DEAD), rank[cap] u32 (arrival order in cell), slots[cap] u32
-//   cell_count[cells+1], cell_start[cells+1] u32 (= the reference's neighbor_grid_indices)
+//   key[cap] u32 (next cell id or DEAD), rank[cap] u32 (place inside the cell), slots[cap] u32
+//   skey[2][cap] u32 packed (cy << 16 | cx) cell of each sorted agent (unfused K_KEY only)
+//   cell_count[cells+1], cell_start[2][cells+1] u32 (= the reference's neighbor_grid_indices;
+//   ping-pong: the gather sort form reads last tick's while writing this tick's)
 //   field maps: distance_map + n potential maps, row-major (y, x) f32
+// Kernels per tick in steady state: count -> scan -> write (-> reorder: no-op) -> force.
 #pragma once
 
 #include "device_math.hpp"
@@ -31,7 +34,6 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t n_
     const uint32_t q = n_blocks / 8u, r = n_blocks % 8u, xcd = b % 8u;
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
 }
-
 
 struct GridView {
     float unit;

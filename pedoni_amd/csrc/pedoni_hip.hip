@@ -963,7 +963,6 @@ int pedoni_hip_download(PedoniModel* m, float* pos_xy, uint32_t* destination, fl
     TRY(copy(vel_xy, m->d_vel[m->pv], sizeof(float2)));
     TRY(copy(desired_speed, m->d_v0[m->vd], sizeof(float)));
     TRY(copy(destination, m->d_dest[m->vd], sizeof(uint32_t)));
-    (void)0;
     HIP_TRY(hipStreamSynchronize(m->stream));
     return PEDONI_OK;
 }
