@@ -293,10 +293,10 @@ __device__ __forceinline__ v2 field_coord(const FieldView& f, v2 pos)
 #define PEDONI_COS_PHI (-0.17364817766693036f) /* sfm.rs:16 */
 
 // force on an agent from a neighbour, given difference = pos - pos_i with
-// |difference|^2 <= 4 already established (sfm.rs:137-153)
+// |difference|^2 <= 4 already established (sfm.rs:137-153), before the field-of-view test
 template <int MODE>
-__device__ __forceinline__ void pair_force_from_difference(v2 difference, v2 e, v2 vel_i, v2& acc,
-                                                           const uint64_t* tab)
+__device__ __forceinline__ v2 pair_force_raw(v2 difference, v2 vel_i, const uint64_t* tab,
+                                             bool& ill_conditioned)
 {
     float distance_squared = dot(difference, difference); // :132
     float distance = fsqrt<MODE>(distance_squared);      // :137
@@ -306,13 +306,42 @@ __device__ __forceinline__ void pair_force_from_difference(v2 difference, v2 e, 
     float t1_length = length<MODE>(t1);                  // :142
     float t2 = distance + t1_length;                     // :143
     float vl = length<MODE>(vel_i) * 0.1f;
-    float b = fsqrt<MODE>(t2 * t2 - vl * vl) * 0.5f;     // :144
+    float t2_sq = t2 * t2, b_arg = t2_sq - vl * vl;
+    // a neighbour about to step onto the agent: t2 -> |v| dt and the difference cancels
+    ill_conditioned = !(b_arg * 8.0f > t2_sq);
+    float b = fsqrt<MODE>(b_arg) * 0.5f;                 // :144
 
     v2 nabla_b = vdiv<MODE>((direction + vdiv<MODE>(t1, t1_length)) * t2, 4.0f * b); // :146
     float k = (2.1f / 0.3f) * fexp<MODE>(div_03<MODE>(-b), tab);                   // :147
-    v2 force = nabla_b * k;
+    return nabla_b * k;
+}
 
-    if (dot(e, -force) < length<MODE>(force) * PEDONI_COS_PHI) // :149
+// PEDONI_MATH_EXACT: the reference's arithmetic, bit for bit.
+// PEDONI_MATH_FAST: hardware rcp / rsq / sqrt / exp (about 1e-6 relative on the force), but
+// the one DISCONTINUOUS decision of the force law -- halving a force that comes from outside
+// the 200-degree field of view (:149-150) -- is never left to approximate numbers: when the
+// test lies within 1e-4 |f| of its boundary the pair is recomputed exactly (rare, so cheap
+// even as a divergent branch).  So is a pair whose `t2^2 - (|v| dt)^2` cancels to less than
+// an eighth of t2^2 (a neighbour within ~|v| dt, heading straight at the agent): there the
+// 1-ulp error of sqrt/rcp would be amplified up to 1000-fold.  The goal direction `e` is
+// exact in both modes.  Every agent then meets the 1e-5 bar; no decision flips.
+template <int MODE>
+__device__ __forceinline__ void pair_force_from_difference(v2 difference, v2 e, v2 vel_i, v2& acc,
+                                                           const uint64_t* tab)
+{
+    bool redo;
+    v2 force = pair_force_raw<MODE>(difference, vel_i, tab, redo);
+    float lhs = dot(e, -force), len = length<MODE>(force);
+    float rhs = len * PEDONI_COS_PHI;
+    if constexpr (MODE != 0) {
+        // ambiguous (or NaN) field-of-view test, or a cancelling b: evaluate exactly
+        if (redo || !(__builtin_fabsf(lhs - rhs) > 1e-4f * len)) {
+            force = pair_force_raw<0>(difference, vel_i, tab, redo);
+            lhs = dot(e, -force);
+            rhs = length<0>(force) * PEDONI_COS_PHI;
+        }
+    }
+    if (lhs < rhs)                                       // :149
         force = force * 0.5f;                            // :150
     acc = acc + force;                                   // :153
 }

@@ -521,7 +521,7 @@ __device__ __forceinline__ v2 goal_direction(const FieldView& f, v2 pos, uint32_
 {
     v2 q = field_coord(f, pos);
     v2 g = sobel_fast(f.potential_maps[dest], f.rows, f.cols, q.x, q.y, nullptr);
-    return normalize<MODE>(g);
+    return normalize<0>(g); // exact in both math modes: `e` feeds the field-of-view decision
 }
 
 // obstacle force from the distance map, sfm.rs:188-192
