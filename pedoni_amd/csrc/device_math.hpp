@@ -26,17 +26,50 @@ __device__ __forceinline__ float dot(v2 a, v2 b) { return (a.x * b.x) + (a.y * b
 // ---- division / sqrt / exp by math mode -------------------------------------------
 template <int MODE> __device__ __forceinline__ float fdiv(float a, float b)
 {
+#ifdef PEDONI_EXP_DIV
+    return a * __builtin_amdgcn_rcpf(b);
+#endif
     if constexpr (MODE == 0) return a / b;             // IEEE, correctly rounded
     else return a * __builtin_amdgcn_rcpf(b);
 }
 template <int MODE> __device__ __forceinline__ float frcp(float b)
 {
+#ifdef PEDONI_EXP_DIV
+    return __builtin_amdgcn_rcpf(b);
+#endif
     if constexpr (MODE == 0) return 1.0f / b;
     else return __builtin_amdgcn_rcpf(b);
 }
+// Correctly rounded sqrt.  hipcc's expansion of sqrtf is v_sqrt_f32 (1 ulp) plus a one-ulp
+// correction from two fma residuals, wrapped in a 2^32 rescale for x < 2^-96 and a class test
+// for 0 / inf / NaN: 16 VALU instructions.  For 2^-96 <= x < inf the wrap is the identity,
+// so the bare correction (sqrt_core) gives the very same bits; anything else (0, denormal,
+// tiny, negative, inf, NaN) takes the compiler's form.  Checked against the host's sqrtf on
+// every non-negative float (tools/exhaustive_sqrt.py).
+__device__ __noinline__ float sqrt_generic(float a) { return __builtin_sqrtf(a); }
+constexpr uint32_t SQRT_CORE_LO = 0x0F800000u;   // bits of 2^-96
+constexpr uint32_t SQRT_CORE_SPAN = 0x70000000u; // up to, not including, +inf
+// < SQRT_CORE_SPAN iff sqrt_core(a) is valid
+__device__ __forceinline__ uint32_t sqrt_core_measure(float a) { return __float_as_uint(a) - SQRT_CORE_LO; }
+__device__ __forceinline__ float sqrt_core(float a)
+{
+    float s = __builtin_amdgcn_sqrtf(a);
+    float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    float r_dn = __builtin_fmaf(-s_dn, s, a);
+    float r_up = __builtin_fmaf(-s_up, s, a);
+    s = r_dn <= 0.0f ? s_dn : s;
+    s = r_up > 0.0f ? s_up : s;
+    return s;
+}
+__device__ __forceinline__ float sqrt_rn(float a)
+{
+    if (__builtin_expect(sqrt_core_measure(a) < SQRT_CORE_SPAN, 1)) return sqrt_core(a);
+    return sqrt_generic(a);
+}
 template <int MODE> __device__ __forceinline__ float fsqrt(float a)
 {
-    if constexpr (MODE == 0) return __builtin_sqrtf(a); // correctly rounded
+    if constexpr (MODE == 0) return sqrt_rn(a);         // correctly rounded
     else return __builtin_amdgcn_sqrtf(a);
 }
 
@@ -71,11 +104,8 @@ __device__ const uint64_t EXP2F_TAB[32] = {
     0x3fef5818dcfba487, 0x3fef7c97337b9b5f, 0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
 };
 
-// Rust's f32::exp is the host libm's expf.  glibc >= 2.27 computes it in double with
-// the table above and a cubic, using FMA on x86-64 (multiarch variant); this replays
-// that sequence operation for operation in f64, so the result equals the host's bit
-// for bit (verified against glibc 2.35 on all 2.2e9 floats in [-104, 88] but two).
-__device__ __forceinline__ float exp_glibc(float x, const uint64_t* tab)
+// the arithmetic of glibc's expf for |x| < 88 (no special cases)
+__device__ __forceinline__ float exp_glibc_core(float x, const uint64_t* tab)
 {
     const double N = 32.0;
     const double InvLn2N = 0x1.71547652b82fep+0 * N;
@@ -83,15 +113,6 @@ __device__ __forceinline__ float exp_glibc(float x, const uint64_t* tab)
     const double C0 = 0x1.c6af84b912394p-5 / N / N / N;
     const double C1 = 0x1.ebfce50fac4f3p-3 / N / N;
     const double C2 = 0x1.62e42ff0c52d6p-1 / N;
-
-    uint32_t ux = __float_as_uint(x);
-    uint32_t abstop = (ux >> 20) & 0x7ff;
-    if (abstop >= 0x42b) { // |x| >= 88 or NaN
-        if (ux == 0xff800000u) return 0.0f;
-        if (abstop >= 0x7f8) return x + x;
-        if (x > 0x1.62e42ep6f) return __builtin_inff();
-        if (x < -0x1.9fe368p6f) return 0.0f;
-    }
     double xd = (double)x;
     double z = InvLn2N * xd;
     double kd = z + SHIFT;
@@ -109,8 +130,29 @@ __device__ __forceinline__ float exp_glibc(float x, const uint64_t* tab)
     return (float)y;
 }
 
+
+// Rust's f32::exp is the host libm's expf.  glibc >= 2.27 computes it in double with
+// the table above and a cubic, using FMA on x86-64 (multiarch variant); this replays
+// that sequence operation for operation in f64, so the result equals the host's bit
+// for bit (verified against glibc 2.35 on all 2.2e9 floats in [-104, 88] but two).
+__device__ __forceinline__ float exp_glibc(float x, const uint64_t* tab)
+{
+    uint32_t ux = __float_as_uint(x);
+    uint32_t abstop = (ux >> 20) & 0x7ff;
+    if (abstop >= 0x42b) { // |x| >= 88 or NaN
+        if (ux == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8) return x + x;
+        if (x > 0x1.62e42ep6f) return __builtin_inff();
+        if (x < -0x1.9fe368p6f) return 0.0f;
+    }
+    return exp_glibc_core(x, tab);
+}
+
 template <int MODE> __device__ __forceinline__ float fexp(float x, const uint64_t* tab)
 {
+#ifdef PEDONI_EXP_EXP
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#endif
     if constexpr (MODE == 0) return exp_glibc(x, tab);
     else return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
 }
@@ -125,6 +167,9 @@ template <int MODE> __device__ __forceinline__ v2 normalize(v2 a)
 }
 template <int MODE> __device__ __forceinline__ v2 vdiv(v2 a, float s)
 {
+#ifdef PEDONI_EXP_DIV
+    { float r = __builtin_amdgcn_rcpf(s); return mk(a.x * r, a.y * r); }
+#endif
     if constexpr (MODE == 0) return mk(a.x / s, a.y / s);
     else { float r = __builtin_amdgcn_rcpf(s); return mk(a.x * r, a.y * r); }
 }
@@ -316,6 +361,50 @@ __device__ __forceinline__ v2 pair_force_raw(v2 difference, v2 vel_i, const uint
     return nabla_b * k;
 }
 
+// Hot form of the exact pair force: the same operations as pair_force_raw<0> and the two
+// sides of the field-of-view test, with the range tests of the five square roots, of
+// x / 0.3 and of exp folded into ONE unsigned maximum (`worst`) instead of a branch each:
+// every sqrt argument must lie in [2^-96, inf) and b below 26 (so |b / 0.3| < 88); then
+// sqrt_core, the fma form of x / 0.3 and exp_glibc_core ARE the generic functions.  A pair
+// with anything else (zero velocity, coincident agents, NaN, ...) returns
+// worst >= SQRT_CORE_SPAN and is evaluated by the generic path instead.
+__device__ __forceinline__ uint32_t pair_force_hot(v2 difference, v2 e, v2 vel_i, const uint64_t* tab,
+                                                   v2& force, float& lhs, float& rhs)
+{
+    float distance_squared = dot(difference, difference); // :132
+    uint32_t worst = sqrt_core_measure(distance_squared);
+    float distance = sqrt_core(distance_squared);        // :137
+    v2 direction = difference * (1.0f / distance);       // :138 normalize()
+
+    v2 t1 = difference - vel_i * 0.1f;                   // :141
+    float t1_sq = dot(t1, t1);
+    worst = max(worst, sqrt_core_measure(t1_sq));
+    float t1_length = sqrt_core(t1_sq);                  // :142
+    float t2 = distance + t1_length;                     // :143
+    float v_sq = dot(vel_i, vel_i);
+    worst = max(worst, sqrt_core_measure(v_sq));
+    float vl = sqrt_core(v_sq) * 0.1f;
+    float b_arg = t2 * t2 - vl * vl;
+    worst = max(worst, sqrt_core_measure(b_arg));
+    float b = sqrt_core(b_arg) * 0.5f;                   // :144
+    // b >= 2^-49 by the test on b_arg; b < 26 keeps x = -b / 0.3 inside (-88, -2^-100]
+    worst = max(worst, __float_as_uint(b) + (SQRT_CORE_SPAN - 0x41D00000u));
+
+    v2 q = mk(t1.x / t1_length, t1.y / t1_length);
+    v2 num = (direction + q) * t2;
+    float den = 4.0f * b;
+    v2 nabla_b = mk(num.x / den, num.y / den);           // :146
+    float x = __builtin_fmaf(-b, 0x1.aaaaaap+1f, -b * -0x1.c71c6ep-25f); // -b / 0.3, see div_03
+    float k = (2.1f / 0.3f) * exp_glibc_core(x, tab);    // :147
+    force = nabla_b * k;
+
+    lhs = dot(e, -force);                                // :149
+    float f_sq = dot(force, force);
+    worst = max(worst, sqrt_core_measure(f_sq));
+    rhs = sqrt_core(f_sq) * PEDONI_COS_PHI;
+    return worst;
+}
+
 // PEDONI_MATH_EXACT: the reference's arithmetic, bit for bit.
 // PEDONI_MATH_FAST: hardware rcp / rsq / sqrt / exp (about 1e-6 relative on the force), but
 // the one DISCONTINUOUS decision of the force law -- halving a force that comes from outside
@@ -330,10 +419,19 @@ __device__ __forceinline__ void pair_force_from_difference(v2 difference, v2 e, 
                                                            const uint64_t* tab)
 {
     bool redo;
-    v2 force = pair_force_raw<MODE>(difference, vel_i, tab, redo);
-    float lhs = dot(e, -force), len = length<MODE>(force);
-    float rhs = len * PEDONI_COS_PHI;
-    if constexpr (MODE != 0) {
+    v2 force;
+    float lhs, rhs;
+    if constexpr (MODE == 0) {
+        if (__builtin_expect(pair_force_hot(difference, e, vel_i, tab, force, lhs, rhs) >= SQRT_CORE_SPAN, 0)) {
+            force = pair_force_raw<0>(difference, vel_i, tab, redo);
+            lhs = dot(e, -force);
+            rhs = length<0>(force) * PEDONI_COS_PHI;
+        }
+    } else {
+        force = pair_force_raw<MODE>(difference, vel_i, tab, redo);
+        float len = length<MODE>(force);
+        lhs = dot(e, -force);
+        rhs = len * PEDONI_COS_PHI;
         // ambiguous (or NaN) field-of-view test, or a cancelling b: evaluate exactly
         if (redo || !(__builtin_fabsf(lhs - rhs) > 1e-4f * len)) {
             force = pair_force_raw<0>(difference, vel_i, tab, redo);

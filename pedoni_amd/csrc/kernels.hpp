@@ -678,7 +678,6 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
 {
     __shared__ uint64_t tab[32];
     __shared__ float4 queue_all[FORCE_WAVES][SLOTS * 64];
-    __shared__ float2 e_all[FORCE_WAVES][64];
     __shared__ unsigned char owner_all[FORCE_WAVES][SLOTS * 64];
     if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
     __syncthreads();
@@ -686,7 +685,6 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float4* queue = queue_all[wave];
     unsigned char* owner_of = owner_all[wave];
-    float2* e_lds = e_all[wave];
     const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
     uint32_t id = a.base + block * blockDim.x + threadIdx.x;
     uint32_t n = *a.live_count;
@@ -741,7 +739,6 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
             }
         }
     }
-    e_lds[lane] = make_float2(e.x, e.y);
     const uint32_t cnt = (a.ablate & 4) ? 0u : n0 + n1 + n2;
     uint32_t max_cnt = cnt;
 #pragma unroll
@@ -800,11 +797,14 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
         // ---- phase 2: one pair force per lane, no divergence, no global memory ----------
         for (uint32_t q0 = 0; q0 < qlen; q0 += 64) {
             uint32_t q = q0 + lane;
-            if (q < qlen) {
+            const bool busy = q < qlen;
+            // the owner's goal direction, straight from its registers (every lane takes part)
+            const int own = busy ? (int)owner_of[q] : (int)lane;
+            const float eo_x = __shfl(e.x, own, 64), eo_y = __shfl(e.y, own, 64);
+            if (busy) {
                 float4 en = queue[q];
-                float2 eo = e_lds[owner_of[q]];
                 v2 f = mk(0.0f, 0.0f);
-                pair_force_from_difference<MODE>(mk(en.x, en.y), mk(eo.x, eo.y), mk(en.z, en.w), f, tab);
+                pair_force_from_difference<MODE>(mk(en.x, en.y), mk(eo_x, eo_y), mk(en.z, en.w), f, tab);
                 reinterpret_cast<float2*>(&queue[q])[0] = make_float2(f.x, f.y);
             }
         }
