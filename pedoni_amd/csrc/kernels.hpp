@@ -11,7 +11,8 @@
 //   cell_count[cells+1], cell_start[2][cells+1] u32 (= the reference's neighbor_grid_indices;
 //   ping-pong: the gather sort form reads last tick's while writing this tick's)
 //   field maps: distance_map + n potential maps, row-major (y, x) f32
-// Kernels per tick in steady state: count -> scan -> write (-> reorder: no-op) -> force.
+// Kernels per tick in steady state: scan -> place (-> reorder: no-op) -> force; the per-cell
+// counts the scan consumes are accumulated by the force kernel's tail (integer atomics).
 #pragma once
 
 #include "device_math.hpp"
@@ -102,7 +103,7 @@ __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __res
                            const HaloIn* __restrict__ halo, FieldView field, GridView grid,
                            int32_t band_lo, int32_t band_hi, const uint32_t* __restrict__ skey_old,
                            int32_t force_general, uint32_t parity, SortFlags* __restrict__ flags,
-                           uint32_t* __restrict__ key)
+                           uint32_t* __restrict__ key, uint32_t* __restrict__ cell_count)
 {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0 && force_general) atomicOr(&flags->far[parity], 1u);
@@ -138,6 +139,7 @@ __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __res
         }
     }
     key[i] = k;
+    if (k != DEAD) atomicAdd(&cell_count[k], 1u);   // integer, so exact in any arrival order
 }
 
 // the three old index ranges that can hold members of new cell (cx, cy)
@@ -158,10 +160,7 @@ __device__ __forceinline__ CellRanges old_ranges(const uint32_t* __restrict__ cs
     return r;
 }
 
-// ---- K_COUNT (timed with PEDONI_K_BIN) ------------------------------------------------------
-// gather form: agent j scans the three old ranges of its NEW cell once, in index order;
-// rank = members before j = its place in the reference's per-cell list, and the last
-// member publishes the cell's count (cell_count was zeroed by the previous scan).
+// ---- which cells sort in which form ----------------------------------------------------------
 // In a sharded run the cells of rows <= lo and >= hi-1 (ghost rows and the owned rows next
 // to them) also receive the exchanged lists, which sit outside the old ranges: those cells
 // always take the general form; all other rows keep the gather form.
@@ -170,36 +169,6 @@ __device__ __forceinline__ bool general_cell(const SortFlags* flags, uint32_t pa
                                              int32_t cy)
 {
     return flags->far[parity] != 0 || (b.sharded && (cy <= b.lo || cy >= b.hi - 1));
-}
-
-__global__ void count_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
-                             GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
-                             const SortFlags* __restrict__ flags, uint32_t parity,
-                             uint32_t* __restrict__ cell_count, uint32_t* __restrict__ rank)
-{
-    uint32_t j = i0 + xcd_contiguous_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    // the NEXT tick's flag is raised by this tick's update_states and the next K_KEY; it can
-    // be cleared here because K_KEY of this tick has finished and nothing reads it now
-    if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<SortFlags*>(flags)->far[parity ^ 1u] = 0;
-    if (j >= n_total) return;
-    uint32_t c = key[j];
-    if (c == DEAD) return;
-    int32_t cy = (int32_t)(c / (uint32_t)grid.cols), cx = (int32_t)(c - (uint32_t)cy * (uint32_t)grid.cols);
-    if (!general_cell(flags, parity, band, cy)) {
-        CellRanges r = old_ranges(cs_old, grid, cx, cy);
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            for (uint32_t i = r.lo[k]; i < r.hi[k]; ++i) {
-                uint32_t hit = key[i] == c ? 1u : 0u;
-                total += hit;
-                before += (i < j) ? hit : 0u;
-            }
-        rank[j] = before;
-        if (before + 1 == total) cell_count[c] = total;
-    } else {
-        rank[j] = atomicAdd(&cell_count[c], 1u);   // general form: provisional arrival rank
-    }
 }
 
 // no-grid variant (sfm.rs:78-88): survivors keep their order; key = 1/0 flag to be scanned
@@ -392,7 +361,7 @@ scan_single_kernel(uint32_t* __restrict__ in, uint32_t n, uint32_t base, uint32_
     }
 }
 
-// ---- K_WRITE (PEDONI_K_SLOT) ----------------------------------------------------------------
+// ---- K_PLACE (PEDONI_K_SLOT): rank inside the cell + move ------------------------------------
 struct SoA {
     const float2* pos_in; const float2* vel_in; const float* v0_in; const uint32_t* dest_in;
     float2* pos_out; float2* vel_out; float* v0_out; uint32_t* dest_out;
@@ -408,22 +377,39 @@ __device__ __forceinline__ void move_agent(const SoA& a, uint32_t from, uint32_t
     a.skey_out[to] = packed;
 }
 
-__global__ void write_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ rank,
-                             uint32_t i0, uint32_t n_total, GridView grid, BandView band,
-                             const uint32_t* __restrict__ cs_new,
-                             const SortFlags* __restrict__ flags, uint32_t parity, SoA a,
+// Per-cell member counts are already in cell_count when the pass starts: every key that is
+// stored -- by the force kernel's tail, by K_KEY or by the halo unpack -- is followed by one
+// integer atomicAdd on its cell.  The scan turned them into cell_start (and zeroed them).
+//  gather form: agent j scans the old ranges of its NEW cell up to its own index; the members
+//    before it = its place in the reference's per-cell list (sfm.rs:66-75).  Ranges of later
+//    rows start beyond j and are skipped, so on average half of the 3 x 3 block is read.
+//  general form: a provisional slot by a second round of atomics on the (zeroed) counter;
+//    K_REORDER puts the cell in order and zeroes the counter again.
+__global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
+                             GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
+                             const uint32_t* __restrict__ cs_new, SortFlags* __restrict__ flags,
+                             uint32_t parity, uint32_t* __restrict__ cell_count, SoA a,
                              uint32_t* __restrict__ slots)
 {
     uint32_t j = i0 + xcd_contiguous_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    // the NEXT tick's flag is raised by this tick's update_states and the next K_KEY; it can
+    // be cleared here because every key of this tick has been written and nothing reads it now
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags->far[parity ^ 1u] = 0;
     if (j >= n_total) return;
     uint32_t c = key[j];
     if (c == DEAD) return;
-    uint32_t p = cs_new[c] + rank[j];
     uint32_t cy = c / (uint32_t)grid.cols, cx = c - cy * (uint32_t)grid.cols;
-    if (!general_cell(flags, parity, band, (int32_t)cy)) { // gather form: rank is final
-        move_agent(a, j, p, pack_cell(cx, cy));
-    } else {                                       // general form: provisional slot
-        slots[p] = j;
+    if (!general_cell(flags, parity, band, (int32_t)cy)) {
+        CellRanges r = old_ranges(cs_old, grid, (int32_t)cx, (int32_t)cy);
+        uint32_t before = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t hi = min(r.hi[k], j);
+            for (uint32_t i = r.lo[k]; i < hi; ++i) before += key[i] == c ? 1u : 0u;
+        }
+        move_agent(a, j, cs_new[c] + before, pack_cell(cx, cy));
+    } else {
+        slots[cs_new[c] + atomicAdd(&cell_count[c], 1u)] = j;
     }
 }
 
@@ -434,7 +420,8 @@ __global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, ui
                                GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
                                const uint32_t* __restrict__ cs_new,
                                const uint32_t* __restrict__ slots,
-                               const SortFlags* __restrict__ flags, uint32_t parity, SoA a)
+                               const SortFlags* __restrict__ flags, uint32_t parity,
+                               uint32_t* __restrict__ cell_count, SoA a)
 {
     // launched with a small fixed grid: in the common tick (gather form everywhere) every
     // wave leaves after one flag read
@@ -462,6 +449,7 @@ __global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, ui
         uint32_t before = 0;
         for (uint32_t j = base; j < end; ++j) before += slots[j] < i ? 1u : 0u;
         move_agent(a, i, base + before, pack_cell(cx, cy));
+        cell_count[k] = 0;   // the provisional-slot counter, back to zero for the next tick's counts
     }
 }
 
@@ -508,6 +496,7 @@ struct ForceArgs {
     // fused K_KEY of the next sort/despawn pass (null = not requested): the agent's next
     // cell key (or DEAD) and the far-mover flag of the next tick's parity
     uint32_t* key_next;
+    uint32_t* cell_count; // members per cell of the next pass (one atomicAdd per stored key)
     uint32_t key_end;    // stale slots [live, key_end) get DEAD keys
     SortFlags* flags;
     uint32_t parity_next;
@@ -673,8 +662,13 @@ __global__ void force_kernel_simple(ForceArgs a)
 constexpr int FORCE_THREADS = 256;
 constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 
+#ifndef PEDONI_EXP_WAVES
+#define PEDONI_EXP_WAVES_ATTR
+#else
+#define PEDONI_EXP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PEDONI_EXP_WAVES, PEDONI_EXP_WAVES)))
+#endif
 template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
+__global__ void __launch_bounds__(FORCE_THREADS) PEDONI_EXP_WAVES_ATTR force_kernel_queue(ForceArgs a)
 {
     __shared__ uint64_t tab[32];
     __shared__ float4 queue_all[FORCE_WAVES][SLOTS * 64];
@@ -872,6 +866,7 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
             }
         }
         a.key_next[id] = k;
+        if (k != DEAD) atomicAdd(&a.cell_count[k], 1u);
     }
 }
 
@@ -1019,7 +1014,7 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
                                    uint32_t* __restrict__ dest, HaloIn* __restrict__ halo,
                                    FieldView field, GridView grid, int32_t band_lo, int32_t band_hi,
                                    uint32_t parity, SortFlags* __restrict__ flags,
-                                   uint32_t* __restrict__ key)
+                                   uint32_t* __restrict__ key, uint32_t* __restrict__ cell_count)
 {
     // thread t < cap: landing slot base - cap + t (the list is right-aligned against base);
     // thread t >= cap: slot gap_end + (t - cap).  Every slot gets a key -- the record's cell
@@ -1068,6 +1063,7 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
         }
     }
     key[at] = kk;
+    if (kk != DEAD) atomicAdd(&cell_count[kk], 1u);
 }
 
 } // namespace pedoni

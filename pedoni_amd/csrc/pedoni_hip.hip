@@ -105,7 +105,6 @@ struct PedoniModel {
     int pv = 0; // buffer holding current pos/vel
     int vd = 0; // buffer holding current desired_speed/destination
     uint32_t* d_key = nullptr;
-    uint32_t* d_rank = nullptr;
     uint32_t* d_slots = nullptr;
     uint32_t* d_scan_in = nullptr;  // cell_count (grid) or flags (no grid)
     uint32_t* d_cs[2] = {nullptr, nullptr}; // cell_start ping-pong (grid) / prefix (no grid, [0])
@@ -116,6 +115,7 @@ struct PedoniModel {
     uint32_t tick_parity = 0;
     bool have_old = false;          // d_cs[cs] / d_skey[sk] describe the stored order
     bool keys_valid = false;        // d_key[base, live) already holds the next pass's keys (fused in K_FORCE)
+    bool counts_dirty = false;      // d_scan_in holds per-cell counts of keys written since the last scan
     uint32_t scan_cap = 0;
     uint32_t* d_block_sums = nullptr;
     uint32_t block_sums_cap = 0;
@@ -253,10 +253,9 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
         hipFree(m->d_pos[k]); hipFree(m->d_vel[k]); hipFree(m->d_v0[k]); hipFree(m->d_dest[k]);
         m->d_pos[k] = npos[k]; m->d_vel[k] = nvel[k]; m->d_v0[k] = nv0[k]; m->d_dest[k] = ndest[k];
     }
-    hipFree(m->d_key); hipFree(m->d_rank); hipFree(m->d_slots);
+    hipFree(m->d_key); hipFree(m->d_slots);
     hipFree(m->d_skey[0]); hipFree(m->d_skey[1]);
     TRY(dev_alloc(&m->d_key, ncap));
-    TRY(dev_alloc(&m->d_rank, ncap));
     TRY(dev_alloc(&m->d_slots, ncap));
     TRY(dev_alloc(&m->d_skey[0], ncap));
     TRY(dev_alloc(&m->d_skey[1], ncap));
@@ -347,44 +346,48 @@ int sort_despawn(PedoniModel* m)
             Timed t(m, PEDONI_K_BIN);
             if (t.rc) return t.rc;
             if (!m->keys_valid || force_general) {
-                // every stored agent needs its key
+                // every stored agent needs its key (and its cell's count: drop what a fused
+                // update may already have accumulated for keys that are now recomputed)
+                if (m->counts_dirty)
+                    HIP_TRY(hipMemsetAsync(m->d_scan_in, 0, (size_t)(m->n_cells + 1) * sizeof(uint32_t),
+                                           m->stream));
                 hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0, m->stream,
                                    m->d_pos[src], m->d_dest[vsrc], i0, n_total, m->base, m->d_live,
                                    m->gap_end, m->d_halo, m->field, m->grid, m->band_lo, m->band_hi,
-                                   m->d_skey[sk_old], force_general, parity, m->d_flags, m->d_key);
+                                   m->d_skey[sk_old], force_general, parity, m->d_flags, m->d_key,
+                                   m->d_scan_in);
             } else {
-                // own agents got their keys from the last update_states; only agents stored
-                // since then are keyed here (exchanged lists were keyed by halo_unpack_kernel)
+                // own agents got their keys (and counts) from the last update_states; only agents
+                // stored since then are keyed here (exchanged lists: by halo_unpack_kernel)
                 if (m->halo_cap && !m->halo_keys_done)
                     hipLaunchKernelGGL(key_kernel, dim3(blocks_for(m->halo_cap, bs)), dim3(bs), 0,
                                        m->stream, m->d_pos[src], m->d_dest[vsrc], i0, m->base, m->base,
                                        m->d_live, m->gap_end, m->d_halo, m->field, m->grid, m->band_lo,
-                                       m->band_hi, m->d_skey[sk_old], 0, parity, m->d_flags, m->d_key);
+                                       m->band_hi, m->d_skey[sk_old], 0, parity, m->d_flags, m->d_key,
+                                       m->d_scan_in);
                 if (n_total > m->gap_end && !m->halo_keys_done)
                     hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_total - m->gap_end, bs)), dim3(bs),
                                        0, m->stream, m->d_pos[src], m->d_dest[vsrc], m->gap_end, n_total,
                                        m->base, m->d_live, m->gap_end, m->d_halo, m->field, m->grid,
                                        m->band_lo, m->band_hi, m->d_skey[sk_old], 0, parity, m->d_flags,
-                                       m->d_key);
+                                       m->d_key, m->d_scan_in);
             }
-            hipLaunchKernelGGL(count_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
-                               m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
-                               m->d_flags, parity, m->d_scan_in, m->d_rank);
         }
         TRY(run_scan(m, m->d_scan_in + c0, n_scan, /*zero_input=*/1, m->d_cs[cs_new] + c0));
+        m->counts_dirty = false;
         {
             Timed t(m, PEDONI_K_SLOT);
             if (t.rc) return t.rc;
-            hipLaunchKernelGGL(write_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
-                               m->stream, m->d_key, m->d_rank, i0, n_total, m->grid, band,
-                               m->d_cs[cs_new], m->d_flags, parity, soa, m->d_slots);
+            hipLaunchKernelGGL(place_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
+                               m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
+                               m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots);
         }
         {
             Timed t(m, PEDONI_K_REORDER);
             if (t.rc) return t.rc;
             hipLaunchKernelGGL(reorder_kernel, dim3(std::min(blocks_for(n_threads, bs), 1024u)), dim3(bs), 0,
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
-                               m->d_cs[cs_new], m->d_slots, m->d_flags, parity, soa);
+                               m->d_cs[cs_new], m->d_slots, m->d_flags, parity, m->d_scan_in, soa);
         }
         m->cs = cs_new;
         m->sk = sk_new;
@@ -453,6 +456,7 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
     const bool fuse = !acc_out && m->opt.use_neighbor_grid && !m->force_simple && !m->no_fuse_key &&
                       m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
     a.key_next = fuse ? m->d_key : nullptr;
+    a.cell_count = m->d_scan_in;
     a.key_end = m->n_upper;
     a.flags = m->d_flags;
     a.parity_next = m->tick_parity & 1u;
@@ -493,6 +497,9 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         // 0.145 ms at N = 1e6 against 0.151 (8 slots, 4 waves) and 0.22 (16 slots, 2 waves)
         if (fast) hipLaunchKernelGGL((force_kernel_queue<1, 6>), grid, block, 0, stream, a);
         else if (m->force_slots == 8) hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, stream, a);
+#ifdef PEDONI_EXP_SLOTS
+        else if (m->force_slots == PEDONI_EXP_SLOTS) hipLaunchKernelGGL((force_kernel_queue<0, PEDONI_EXP_SLOTS>), grid, block, 0, stream, a);
+#endif
         else hipLaunchKernelGGL((force_kernel_queue<0, 6>), grid, block, 0, stream, a);
     } else {
         if (part != 0) return fail(PEDONI_E_INVALID, "row-segment force launch needs the queue kernel");
@@ -509,6 +516,7 @@ void after_update(PedoniModel* m)
     if (m->n_upper > m->base) m->pv = 1 - m->pv;
     m->keys_valid = m->n_upper > m->base && m->opt.use_neighbor_grid && !m->force_simple &&
                     !m->no_fuse_key && m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
+    if (m->keys_valid) m->counts_dirty = true;
     m->sorted = false;
 }
 
@@ -752,7 +760,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     for (int k = 0; k < 2; ++k) {
         hipFree(m->d_pos[k]); hipFree(m->d_vel[k]); hipFree(m->d_v0[k]); hipFree(m->d_dest[k]);
     }
-    hipFree(m->d_key); hipFree(m->d_rank); hipFree(m->d_slots);
+    hipFree(m->d_key); hipFree(m->d_slots);
     hipFree(m->d_scan_in); hipFree(m->d_cs[0]); hipFree(m->d_cs[1]); hipFree(m->d_block_sums);
     hipFree(m->d_skey[0]); hipFree(m->d_skey[1]); hipFree(m->d_flags);
     hipFree(m->d_live); hipFree(m->d_acc); hipFree(m->d_halo);
@@ -1166,8 +1174,9 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
     hipLaunchKernelGGL(halo_unpack_kernel, dim3(blocks_for(2 * cap_each, 256)), dim3(256), 0,
                        m->stream, below, above, cap_each, m->base, m->n_upper, m->d_pos[m->pv],
                        m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_halo, m->field, m->grid,
-                       m->band_lo, m->band_hi, m->tick_parity & 1u, m->d_flags, m->d_key);
+                       m->band_lo, m->band_hi, m->tick_parity & 1u, m->d_flags, m->d_key, m->d_scan_in);
     HIP_TRY(hipGetLastError());
+    m->counts_dirty = true;
     m->gap_end = m->n_upper;      // the above list starts here
     m->n_upper += cap_each;       // host bound; the device knows the true count
     m->halo_keys_done = true;     // the exchanged agents already carry their keys
