@@ -26,17 +26,11 @@ __device__ __forceinline__ float dot(v2 a, v2 b) { return (a.x * b.x) + (a.y * b
 // ---- division / sqrt / exp by math mode -------------------------------------------
 template <int MODE> __device__ __forceinline__ float fdiv(float a, float b)
 {
-#ifdef PEDONI_EXP_DIV
-    return a * __builtin_amdgcn_rcpf(b);
-#endif
     if constexpr (MODE == 0) return a / b;             // IEEE, correctly rounded
     else return a * __builtin_amdgcn_rcpf(b);
 }
 template <int MODE> __device__ __forceinline__ float frcp(float b)
 {
-#ifdef PEDONI_EXP_DIV
-    return __builtin_amdgcn_rcpf(b);
-#endif
     if constexpr (MODE == 0) return 1.0f / b;
     else return __builtin_amdgcn_rcpf(b);
 }
@@ -150,9 +144,6 @@ __device__ __forceinline__ float exp_glibc(float x, const uint64_t* tab)
 
 template <int MODE> __device__ __forceinline__ float fexp(float x, const uint64_t* tab)
 {
-#ifdef PEDONI_EXP_EXP
-    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
-#endif
     if constexpr (MODE == 0) return exp_glibc(x, tab);
     else return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
 }
@@ -167,9 +158,6 @@ template <int MODE> __device__ __forceinline__ v2 normalize(v2 a)
 }
 template <int MODE> __device__ __forceinline__ v2 vdiv(v2 a, float s)
 {
-#ifdef PEDONI_EXP_DIV
-    { float r = __builtin_amdgcn_rcpf(s); return mk(a.x * r, a.y * r); }
-#endif
     if constexpr (MODE == 0) return mk(a.x / s, a.y / s);
     else { float r = __builtin_amdgcn_rcpf(s); return mk(a.x * r, a.y * r); }
 }

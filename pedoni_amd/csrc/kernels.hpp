@@ -662,13 +662,8 @@ __global__ void force_kernel_simple(ForceArgs a)
 constexpr int FORCE_THREADS = 256;
 constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 
-#ifndef PEDONI_EXP_WAVES
-#define PEDONI_EXP_WAVES_ATTR
-#else
-#define PEDONI_EXP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PEDONI_EXP_WAVES, PEDONI_EXP_WAVES)))
-#endif
 template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS) PEDONI_EXP_WAVES_ATTR force_kernel_queue(ForceArgs a)
+__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
 {
     __shared__ uint64_t tab[32];
     __shared__ float4 queue_all[FORCE_WAVES][SLOTS * 64];

@@ -497,9 +497,6 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         // 0.145 ms at N = 1e6 against 0.151 (8 slots, 4 waves) and 0.22 (16 slots, 2 waves)
         if (fast) hipLaunchKernelGGL((force_kernel_queue<1, 6>), grid, block, 0, stream, a);
         else if (m->force_slots == 8) hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, stream, a);
-#ifdef PEDONI_EXP_SLOTS
-        else if (m->force_slots == PEDONI_EXP_SLOTS) hipLaunchKernelGGL((force_kernel_queue<0, PEDONI_EXP_SLOTS>), grid, block, 0, stream, a);
-#endif
         else hipLaunchKernelGGL((force_kernel_queue<0, 6>), grid, block, 0, stream, a);
     } else {
         if (part != 0) return fail(PEDONI_E_INVALID, "row-segment force launch needs the queue kernel");

@@ -267,6 +267,42 @@ def test_coincident_agents_go_nan_then_despawn(hip, oracle):
     gpu.close()
 
 
+def test_pair_force_outside_the_hot_range_takes_the_generic_path(hip, oracle):
+    """The exact pair force has a hot form valid for sqrt arguments in [2^-96, inf) and b < 26
+    (device_math.hpp pair_force_hot) and a generic form for everything else.  Neighbours
+    with zero, denormal-square, huge and overflowing velocities, and separations whose
+    square is denormal or underflows, must still match the oracle bit for bit."""
+    sc = box_scenario(40.0)
+    field = oracle_field(oracle, sc)
+    rng = np.random.default_rng(77)
+    n = 600
+    pos = rng.uniform(18.0, 22.0, (n, 2)).astype(np.float32)          # ~37 agents / m^2
+    tiny = np.array([[1e-3, 1e-3], [1e-3 + 1e-12, 1e-3], [1e-3, 1e-3 + 3e-20], [1.0001e-3, 1e-3],
+                     [2e-23, 1e-23], [3e-23, 1e-23]], np.float32)      # d^2 normal, tiny, denormal, 0
+    pos = np.concatenate([pos, tiny])
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    special = np.array([[0, 0], [1e-25, 0], [1e-20, 1e-20], [250.0, 0], [600.0, -600.0], [1e10, 1e10],
+                        [1e19, 0], [3e19, 3e19], [np.inf, 0], [-1e30, 1e5]], np.float32)
+    for k, v in enumerate(special):
+        vel[k::40][: 15] = v
+    vel[n:] = [[0, 0], [1e-25, 0], [0.3, 0.1], [600.0, 0], [0, 0], [1e-30, 0]]
+    dest = np.ones(len(pos), np.uint32)
+    v0 = np.full(len(pos), 1.3, np.float32)
+    cpu = oracle.OracleModel(sc.field.size)
+    gpu = _make_hip(hip, sc, field)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    with np.errstate(all="ignore"):
+        want = cpu.calc_accelerations(field)
+        got = gpu.calc_accelerations(cpu.get_pedestrian_count())
+        assert bit_equal(got, want).all(), f"{np.count_nonzero(~bit_equal(got, want))} components differ"
+        cpu.update_states(field)
+        gpu.update_states()
+        _assert_state_equal(gpu.download(), cpu.download(), "integrated")
+    gpu.close()
+
+
 def test_many_agents_in_one_cell_keep_insertion_order(hip, oracle):
     """Stable in-cell order (sfm.rs:67-68) with far more cell-mates than a wavefront."""
     sc = box_scenario(40.0)
