@@ -78,11 +78,11 @@ typedef struct {
     uint64_t launches[PEDONI_N_KERNELS];
 } PedoniKernelTimes;
 /* indices into PedoniKernelTimes */
-#define PEDONI_K_BIN 0       /* cell key + despawn test, per-cell count     */
+#define PEDONI_K_BIN 0       /* cell key + despawn test + cell count of agents stored since the last update */
 #define PEDONI_K_SCAN 1      /* exclusive scan -> neighbor_grid_indices     */
-#define PEDONI_K_SLOT 2      /* stable gather of each cell's agents (or slot) */
+#define PEDONI_K_SLOT 2      /* place: rank inside the new cell + SoA move (or provisional slot) */
 #define PEDONI_K_REORDER 3   /* general form: in-cell rank + SoA scatter     */
-#define PEDONI_K_FORCE 4     /* goal + pair + obstacle force + integrator    */
+#define PEDONI_K_FORCE 4     /* goal + pair + obstacle force + integrator + next key / cell count */
 #define PEDONI_K_HALO_PACK 5
 #define PEDONI_K_HALO_UNPACK 6
 #define PEDONI_K_OTHER 7

@@ -6,7 +6,7 @@
 // Data layout in HBM (structure of arrays, all fp32 / u32):
 //   pos[2][cap] float2, vel[2][cap] float2      ping-pong twice per tick (sort, integrate)
 //   desired_speed[2][cap] f32, destination[2][cap] u32   ping-pong once per tick (sort)
-//   key[cap] u32 (next cell id or DEAD), rank[cap] u32 (place inside the cell), slots[cap] u32
+//   key[cap] u32 (next cell id or DEAD), slots[cap] u32 (general-form scratch)
 //   skey[2][cap] u32 packed (cy << 16 | cx) cell of each sorted agent (unfused K_KEY only)
 //   cell_count[cells+1], cell_start[2][cells+1] u32 (= the reference's neighbor_grid_indices;
 //   ping-pong: the gather sort form reads last tick's while writing this tick's)
