@@ -734,9 +734,15 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     for (int off = 32; off > 0; off >>= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, off, 64));
     max_cnt = __builtin_amdgcn_readfirstlane(max_cnt);
 
+    // candidate s of this lane: index r0 + s, r1 + (s - n0) or r2 + (s - n0 - n1)
+    const uint32_t n01 = n0 + n1, r1s = r1 - n0, r2s = r2 - n01;
+    // a lane without a candidate in some slot reads its own record instead (always a valid
+    // address, already in cache): phase 1 then has no divergent branch around its loads
+    const uint32_t id_safe = valid ? id : a.base;
+
     for (uint32_t base = 0; base < max_cnt; base += SLOTS) {
         // ---- phase 1: cutoff test + compaction ---------------------------------------
-        // three unrolled sub-passes so that the SLOTS position loads, then the survivors'
+        // three unrolled sub-passes so that the SLOTS position loads, then the SLOTS
         // velocity loads, are all in flight together
         uint32_t qlen = 0;       // wave-uniform
         uint32_t passmask = 0;
@@ -746,25 +752,20 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
             uint32_t s = base + k;
-            idx[k] = s < n0 ? r0 + s : (s < n0 + n1 ? r1 + (s - n0) : r2 + (s - n0 - n1));
-            d[k] = make_float2(0.0f, 0.0f);
-            if (s < cnt) d[k] = a.pos[idx[k]];
+            uint32_t i = s + (s < n0 ? r0 : (s < n01 ? r1s : r2s));
+            idx[k] = s < cnt ? i : id_safe;
+            d[k] = a.pos[idx[k]];
         }
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
-            bool pass = false;
-            if (base + k < cnt) {
-                float dx = pos.x - d[k].x;                        // :131
-                float dy = pos.y - d[k].y;
-                float d2 = (dx * dx) + (dy * dy);                 // :132
-                pass = !(d2 > 4.0f) && idx[k] != id;              // :130,133
-                d[k] = make_float2(dx, dy);
-            }
-            vi[k] = make_float2(0.0f, 0.0f);
-            if (pass) {
-                vi[k] = a.vel[idx[k]];                            // :140
-                passmask |= 1u << k;
-            }
+            float dx = pos.x - d[k].x;                            // :131
+            float dy = pos.y - d[k].y;
+            float d2 = (dx * dx) + (dy * dy);                     // :132
+            // :130,133 (idx == id also marks "no candidate in this slot")
+            bool pass = !(d2 > 4.0f) && idx[k] != id_safe;
+            d[k] = make_float2(dx, dy);
+            vi[k] = a.vel[pass ? idx[k] : id_safe];               // :140
+            passmask |= pass ? 1u << k : 0u;
         }
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
