@@ -209,7 +209,8 @@ int pedoni_hip_owned_count(PedoniModel* m, int32_t* count);
 
 /* [ext] device self-test hooks used by tests/: evaluate one device math primitive over
  * host arrays (op: 0 = a/b, 1 = sqrt(a), 2 = exp(a), 3 = a/0.3f, 4 = a/0.2f,
- * 5 = Rust-style `a as i32`, result bits returned in the float) */
+ * 5 = Rust-style `a as i32`, result bits returned in the float, 6 = a/b by the pair
+ * force's unscaled division core -- equal to a/b wherever pair_force_hot uses it) */
 int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mode, const float* a,
                              const float* b, float* out, uint32_t n);
 

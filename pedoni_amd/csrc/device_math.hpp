@@ -322,6 +322,34 @@ __device__ __forceinline__ v2 field_coord(const FieldView& f, v2 pos)
     return mk(pos.x / f.unit - 0.5f, pos.y / f.unit - 0.5f);
 }
 
+// ---- hot-path division ------------------------------------------------------------------
+// hipcc expands a / b to v_div_scale x2, v_rcp, a Newton step on the reciprocal, two
+// residual corrections of the quotient, v_div_fmas, v_div_fixup.  Where neither operand
+// needs rescaling (b normal, |a| >= 2^-103, |a / b| in [2^-126, 2^96)) and no operand is
+// 0 / inf / NaN, scale, fmas and fixup are identities and what remains is the arithmetic
+// below -- the same instructions on the same values, hence the same bits -- and the
+// reciprocal part is shared by quotients with one denominator.  pair_force_hot guarantees
+// that domain through its folded range test (it rejects quotients below 2^-50, which covers
+// every numerator small enough to be rescaled).
+struct Recip { float d, y; };
+__device__ __forceinline__ Recip recip_refined(float d)
+{
+    float y = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, y, 1.0f);
+    Recip r;
+    r.d = d;
+    r.y = __builtin_fmaf(e, y, y);
+    return r;
+}
+__device__ __forceinline__ float div_core(float n, Recip r)
+{
+    float q = n * r.y;
+    float e = __builtin_fmaf(-r.d, q, n);
+    q = __builtin_fmaf(e, r.y, q);
+    e = __builtin_fmaf(-r.d, q, n);
+    return __builtin_fmaf(e, r.y, q);
+}
+
 // ---- pair force (sfm.rs:131-153) -----------------------------------------------------
 #define PEDONI_COS_PHI (-0.17364817766693036f) /* sfm.rs:16 */
 
@@ -351,9 +379,10 @@ __device__ __forceinline__ v2 pair_force_raw(v2 difference, v2 vel_i, const uint
 
 // Hot form of the exact pair force: the same operations as pair_force_raw<0> and the two
 // sides of the field-of-view test, with the range tests of the five square roots, of
-// x / 0.3 and of exp folded into ONE unsigned maximum (`worst`) instead of a branch each:
-// every sqrt argument must lie in [2^-96, inf) and b below 26 (so |b / 0.3| < 88); then
-// sqrt_core, the fma form of x / 0.3 and exp_glibc_core ARE the generic functions.  A pair
+// x / 0.3, of exp and of the five divisions folded into ONE unsigned maximum (`worst`)
+// instead of a branch each: every sqrt argument must lie in [2^-96, inf), |v| in
+// [2^-48, 2^20), b below 26 (so |b / 0.3| < 88) and no quotient below 2^-50; then sqrt_core,
+// div_core, the fma form of x / 0.3 and exp_glibc_core ARE the generic functions.  A pair
 // with anything else (zero velocity, coincident agents, NaN, ...) returns
 // worst >= SQRT_CORE_SPAN and is evaluated by the generic path instead.
 __device__ __forceinline__ uint32_t pair_force_hot(v2 difference, v2 e, v2 vel_i, const uint64_t* tab,
@@ -362,7 +391,7 @@ __device__ __forceinline__ uint32_t pair_force_hot(v2 difference, v2 e, v2 vel_i
     float distance_squared = dot(difference, difference); // :132
     uint32_t worst = sqrt_core_measure(distance_squared);
     float distance = sqrt_core(distance_squared);        // :137
-    v2 direction = difference * (1.0f / distance);       // :138 normalize()
+    v2 direction = difference * div_core(1.0f, recip_refined(distance)); // :138 normalize()
 
     v2 t1 = difference - vel_i * 0.1f;                   // :141
     float t1_sq = dot(t1, t1);
@@ -370,7 +399,10 @@ __device__ __forceinline__ uint32_t pair_force_hot(v2 difference, v2 e, v2 vel_i
     float t1_length = sqrt_core(t1_sq);                  // :142
     float t2 = distance + t1_length;                     // :143
     float v_sq = dot(vel_i, vel_i);
-    worst = max(worst, sqrt_core_measure(v_sq));
+    // |v| in [2^-48, 2^20): keeps every numerator and denominator below within 2^+-96 of
+    // each other (saturating add: an argument below 2^-96 has wrapped to a huge measure)
+    worst = max(worst, __builtin_elementwise_add_sat(sqrt_core_measure(v_sq),
+                                                     SQRT_CORE_SPAN - 0x44000000u));
     float vl = sqrt_core(v_sq) * 0.1f;
     float b_arg = t2 * t2 - vl * vl;
     worst = max(worst, sqrt_core_measure(b_arg));
@@ -378,10 +410,16 @@ __device__ __forceinline__ uint32_t pair_force_hot(v2 difference, v2 e, v2 vel_i
     // b >= 2^-49 by the test on b_arg; b < 26 keeps x = -b / 0.3 inside (-88, -2^-100]
     worst = max(worst, __float_as_uint(b) + (SQRT_CORE_SPAN - 0x41D00000u));
 
-    v2 q = mk(t1.x / t1_length, t1.y / t1_length);
+    Recip rl = recip_refined(t1_length);
+    v2 q = mk(div_core(t1.x, rl), div_core(t1.y, rl));
     v2 num = (direction + q) * t2;
-    float den = 4.0f * b;
-    v2 nabla_b = mk(num.x / den, num.y / den);           // :146
+    Recip rb = recip_refined(4.0f * b);
+    v2 nabla_b = mk(div_core(num.x, rb), div_core(num.y, rb)); // :146
+    // the four quotients must be >= 2^-50 in magnitude (0x26800000): none is zero and no
+    // numerator was small enough for the generic division to rescale it
+    float q_min = __builtin_fminf(__builtin_fminf(__builtin_fabsf(q.x), __builtin_fabsf(q.y)),
+                                  __builtin_fminf(__builtin_fabsf(nabla_b.x), __builtin_fabsf(nabla_b.y)));
+    worst = max(worst, __float_as_uint(q_min) - 0x26800000u);
     float x = __builtin_fmaf(-b, 0x1.aaaaaap+1f, -b * -0x1.c71c6ep-25f); // -b / 0.3, see div_03
     float k = (2.1f / 0.3f) * exp_glibc_core(x, tab);    // :147
     force = nabla_b * k;

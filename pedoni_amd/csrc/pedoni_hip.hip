@@ -1275,6 +1275,7 @@ __global__ void selftest_kernel(int op, const float* a, const float* b, float* o
     case 3: r = div_03<MODE>(a[i]); break;
     case 4: r = div_02<MODE>(a[i]); break;
     case 5: r = __int_as_float(f32_as_i32(a[i])); break;   // raw i32 bits
+    case 6: r = div_core(a[i], recip_refined(b[i])); break;
     default: r = 0.0f;
     }
     out[i] = r;
@@ -1284,7 +1285,7 @@ __global__ void selftest_kernel(int op, const float* a, const float* b, float* o
 extern "C" int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mode, const float* a,
                                         const float* b, float* out, uint32_t n)
 {
-    if (!a || !out || (op == 0 && !b) || op < 0 || op > 5)
+    if (!a || !out || ((op == 0 || op == 6) && !b) || op < 0 || op > 6)
         return fail(PEDONI_E_INVALID, "selftest: bad arguments");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)

@@ -59,6 +59,26 @@ def test_device_div_sqrt_are_ieee(hip):
         assert bit_equal(abi.selftest_math(1, np.abs(a)), np.sqrt(np.abs(a))).all()
 
 
+def test_device_division_core_is_ieee_in_its_domain(hip):
+    """pair_force_hot divides with the compiler's own Newton/residual arithmetic minus its
+    rescaling wrap (device_math.hpp div_core): identical to IEEE division wherever the hot
+    path uses it -- denominators in [2^-48, 2^20), quotients of magnitude >= 2^-50."""
+    from pedoni_amd import abi
+    rng = np.random.default_rng(61)
+    n = 4_000_000
+    d = np.exp2(rng.uniform(-48, 20, n)).astype(np.float32) * rng.choice([-1.0, 1.0], n).astype(np.float32)
+    q = np.exp2(rng.uniform(-50, 60, n)) * rng.choice([-1.0, 1.0], n)
+    a = (q * d.astype(np.float64)).astype(np.float32)
+    keep = np.isfinite(a) & (np.abs(a) >= 2.0 ** -100) & (np.abs(a.astype(np.float64) / d) >= 2.0 ** -50)
+    a, d = a[keep], d[keep]
+    # plus ordinary magnitudes, where all but a vanishing share of real pairs live
+    a2 = rng.normal(0, 1.5, n).astype(np.float32)
+    d2 = rng.uniform(1e-3, 8.0, n).astype(np.float32)
+    a, d = np.concatenate([a, a2, np.ones(n // 4, np.float32)]), np.concatenate([d, d2, d2[: n // 4]])
+    with np.errstate(all="ignore"):
+        assert bit_equal(abi.selftest_math(6, a, d), a / d).all()
+
+
 def test_device_constant_division_is_ieee(hip):
     """x / 0.3f and x / 0.2f by fma(x, zh, x*zl): exhaustively exact on the host for
     2^-100 <= |x| <= 2^100; here the device form incl. its fallback range."""
