@@ -188,6 +188,11 @@ struct FieldView {
     int32_t rows, cols;
     float unit;
     uint32_t n_maps;
+    // unit is a power of two (the default 0.25 is): x / unit == x * inv_unit for every x --
+    // scaling by a power of two is exact, and overflows / rounds into the denormals exactly
+    // where the division does
+    float inv_unit;
+    int32_t unit_pow2;
 };
 
 // util.rs:30-36 + :53-56: texel or 1e12 when the index is negative / out of shape
@@ -319,6 +324,7 @@ __device__ __forceinline__ v2 sobel_fast(const float* __restrict__ g, int32_t ro
 // it decides which texels are read)
 __device__ __forceinline__ v2 field_coord(const FieldView& f, v2 pos)
 {
+    if (f.unit_pow2) return mk(pos.x * f.inv_unit - 0.5f, pos.y * f.inv_unit - 0.5f);
     return mk(pos.x / f.unit - 0.5f, pos.y / f.unit - 0.5f);
 }
 

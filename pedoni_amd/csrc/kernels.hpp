@@ -701,6 +701,7 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     float desired_speed = 0.0f;
     uint32_t r0 = 0, r1 = 0, r2 = 0, n0 = 0, n1 = 0, n2 = 0;
     bool ghost = false;
+    int32_t ix = 0, iy = 0;   // the agent's cell (kept for the far-mover test of the tail)
     if (valid) {
         float2 p = a.pos[id];
         vv = a.vel[id];
@@ -708,8 +709,8 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
         vel = mk(vv.x, vv.y);
         desired_speed = a.v0[id];
         uint32_t destination = a.dest[id];
-        int32_t ix = f32_as_i32(pos.x / a.grid.unit);            // sfm.rs:113
-        int32_t iy = f32_as_i32(pos.y / a.grid.unit);
+        ix = f32_as_i32(pos.x / a.grid.unit);                    // sfm.rs:113
+        iy = f32_as_i32(pos.y / a.grid.unit);
         ghost = iy < a.band_lo || iy >= a.band_hi;
         if (!ghost) {
             if (a.ablate & 1) e = mk(1.0f, 0.0f);
@@ -835,7 +836,6 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); return; }
 
     // integrator, sfm.rs:245-254
-    const float p_old_x = pos.x, p_old_y = pos.y;
     v2 vel_prev = vel;
     vel = vel + acc * 0.1f;
     float max_len = desired_speed * 1.3f;
@@ -857,8 +857,7 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
             int32_t cy = (int32_t)(c / a.grid.cols), cx = (int32_t)(c - (int64_t)cy * a.grid.cols);
             if (cy >= a.band_lo - 1 && cy <= a.band_hi) {
                 k = (uint32_t)c;
-                int32_t ox = f32_as_i32(p_old_x / a.grid.unit), oy = f32_as_i32(p_old_y / a.grid.unit);
-                if (abs(cx - ox) > 1 || abs(cy - oy) > 1) atomicOr(&a.flags->far[a.parity_next], 1u);
+                if (abs(cx - ix) > 1 || abs(cy - iy) > 1) atomicOr(&a.flags->far[a.parity_next], 1u);
             }
         }
         a.key_next[id] = k;

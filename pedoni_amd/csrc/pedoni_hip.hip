@@ -699,6 +699,13 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
     m->field.rows = (int32_t)field_rows;
     m->field.cols = (int32_t)field_cols;
     m->field.unit = field_unit;
+    {
+        int e = 0;
+        const float mant = std::frexp(field_unit, &e);
+        // 2^-100 .. 2^100: both unit and 1 / unit are normal floats
+        m->field.unit_pow2 = (mant == 0.5f && e > -100 && e < 100) ? 1 : 0;
+        m->field.inv_unit = m->field.unit_pow2 ? 1.0f / field_unit : 0.0f;
+    }
     m->field.n_maps = n_maps;
 
     m->n_obstacles = n_obstacles;

@@ -587,6 +587,28 @@ def test_fast_math_mode_within_1e5(hip, oracle):
         gpu.close()
 
 
+@pytest.mark.parametrize("field_unit,grid_unit", [(0.25, 1.4), (0.5, 2.0), (0.3, 1.4), (0.2, 1.0)])
+def test_field_and_grid_units_pow2_and_not(hip, oracle, field_unit, grid_unit):
+    """`pos / unit` (field.rs:236, neighbor_grid.rs:27): a power-of-two field unit takes the
+    multiply form on the device, any other unit the IEEE division; same bits either way."""
+    sc = random_obstacle_scenario(60.0, 40)
+    field = oracle_field(oracle, sc, unit=field_unit)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 8000, 4, seed=91)
+    cpu = oracle.OracleModel(sc.field.size, neighbor_grid_unit=grid_unit)
+    gpu = _make_hip(hip, sc, field, neighbor_grid_unit=grid_unit, field_grid_unit=field_unit)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    for step in range(4):
+        cpu.update_states(field)
+        gpu.update_states()
+        cpu.spawn_pedestrians(field)
+        gpu.spawn_pedestrians()
+        assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices()), step
+        _assert_state_equal(gpu.download(), cpu.download(), f"step {step}")
+    gpu.close()
+
+
 def test_queue_and_simple_force_kernels_agree(hip, oracle, monkeypatch):
     """The wave-queue force kernel and the one-lane-per-agent kernel are independent
     implementations of sfm.rs:93-241; both must reproduce the oracle bit for bit."""
