@@ -155,6 +155,11 @@ int pedoni_hip_set_spawners(PedoniModel* m, const PedoniSpawner* spawners, uint3
                             uint64_t position_rng_state, uint32_t max_per_tick);
 /* current states of the two streams (to hand spawning back to the host) */
 int pedoni_hip_get_spawn_rng(PedoniModel* m, uint64_t* position_rng_state, uint64_t* speed_rng_state);
+/* [ext] restore the model's desired-speed stream (sfm.rs:54 draws from it), e.g. when a
+ * checkpoint is resumed: with pedoni_hip_download / pedoni_hip_append (full SoA state) and
+ * pedoni_hip_get_spawn_rng this makes the model's state exportable and importable whole
+ * (upstream's list_pedestrians drops velocity and desired speed) */
+int pedoni_hip_set_speed_rng(PedoniModel* m, uint64_t speed_rng_state);
 
 /* [ext] stream / timing */
 /* All launches and copies of the model go to `hip_stream` (a hipStream_t; NULL is HIP's

@@ -94,6 +94,13 @@ int pedoni_simulator_step(const PedoniSimulator* sim, int32_t* step);
 /* Simulator::list_pedestrians (lib.rs:102-104) */
 int pedoni_simulator_list_pedestrians(PedoniSimulator* sim, PedoniPedestrian* out, uint32_t cap,
                                       uint32_t* n);
+/* build-owned checkpoint / resume (upstream has none): step counter, both
+ * generator states and the model's full SoA state; a resumed run continues bit for bit like
+ * the uninterrupted one.  `resume` replaces pedoni_simulator_new (no `once` spawns) and
+ * fails when the file was saved with another scenario or other simulator options. */
+int pedoni_simulator_save_checkpoint(PedoniSimulator* sim, const char* path);
+int pedoni_simulator_resume(const PedoniSimulatorOptions* opt, const PedoniScenario* scenario,
+                            const char* path, PedoniSimulator** out);
 /* pub fields `model`, `field` (lib.rs:20-21), borrowed */
 PedoniModel* pedoni_simulator_model(PedoniSimulator* sim);
 const PedoniField* pedoni_simulator_field(const PedoniSimulator* sim);

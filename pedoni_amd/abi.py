@@ -38,7 +38,7 @@ SYMBOLS = [
     "pedoni_hip_halo_pack", "pedoni_hip_halo_unpack", "pedoni_hip_halo_tick",
     "pedoni_hip_halo_tick_begin", "pedoni_hip_halo_tick_end",
     "pedoni_hip_owned_count",
-    "pedoni_hip_selftest_math", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng",
+    "pedoni_hip_selftest_math", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
 ]
 
 
@@ -268,6 +268,16 @@ class HipModel:
             self._h, _ptr(pos, C.c_float), _ptr(dest, C.c_uint32), _ptr(vel, C.c_float),
             _ptr(v0, C.c_float), C.c_uint32(k), C.byref(n)))
         return pos, dest, vel, v0
+
+    def get_spawn_rng(self):
+        """(position stream, desired-speed stream) generator states."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self._lib, self._lib.pedoni_hip_get_spawn_rng(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def set_speed_rng(self, state: int) -> None:
+        """Restore the desired-speed stream (sfm.rs:54), e.g. from a checkpoint."""
+        _check(self._lib, self._lib.pedoni_hip_set_speed_rng(self._h, C.c_uint64(state)))
 
     def clear(self) -> None:
         _check(self._lib, self._lib.pedoni_hip_clear(self._h))

@@ -172,29 +172,62 @@ int pedoni_field_get_obstacle_distance(const PedoniField* f, float x, float y, f
     return PEDONI_OK;
 }
 
+namespace {
+SimulatorOptions to_options(const PedoniSimulatorOptions* o)
+{
+    SimulatorOptions so;
+    so.backend = o->backend == PEDONI_BACKEND_CPU ? Backend::Cpu
+               : o->backend == PEDONI_BACKEND_GPU ? Backend::Gpu : Backend::Hip;
+    so.neighbor_grid_unit = o->neighbor_grid_unit;
+    so.field_grid_unit = o->field_grid_unit;
+    so.use_neighbor_grid = o->use_neighbor_grid != 0;
+    so.use_distance_map = o->use_distance_map != 0;
+    so.gpu_work_size = (size_t)std::max(o->gpu_work_size, 0);
+    so.math_mode = o->math_mode;
+    so.device = o->device;
+    so.seed = o->seed;
+    return so;
+}
+} // namespace
+
 int pedoni_simulator_new(const PedoniSimulatorOptions* o, const PedoniScenario* scenario, PedoniSimulator** out)
 {
     if (!o || !scenario || !out) return fail(PEDONI_E_INVALID, "null argument");
     return guarded([&] {
-        SimulatorOptions so;
-        so.backend = o->backend == PEDONI_BACKEND_CPU ? Backend::Cpu
-                   : o->backend == PEDONI_BACKEND_GPU ? Backend::Gpu : Backend::Hip;
-        so.neighbor_grid_unit = o->neighbor_grid_unit;
-        so.field_grid_unit = o->field_grid_unit;
-        so.use_neighbor_grid = o->use_neighbor_grid != 0;
-        so.use_distance_map = o->use_distance_map != 0;
-        so.gpu_work_size = (size_t)std::max(o->gpu_work_size, 0);
-        so.math_mode = o->math_mode;
-        so.device = o->device;
-        so.seed = o->seed;
         auto* s = new PedoniSimulator();
         try {
-            s->sim = std::make_unique<Simulator>(so, scenario->sc);
+            s->sim = std::make_unique<Simulator>(to_options(o), scenario->sc);
         } catch (...) {
             delete s;
             throw;
         }
         *out = s;
+        return PEDONI_OK;
+    });
+}
+
+int pedoni_simulator_resume(const PedoniSimulatorOptions* o, const PedoniScenario* scenario,
+                            const char* path, PedoniSimulator** out)
+{
+    if (!o || !scenario || !path || !out) return fail(PEDONI_E_INVALID, "null argument");
+    return guarded([&] {
+        auto* s = new PedoniSimulator();
+        try {
+            s->sim = Simulator::resume(to_options(o), scenario->sc, path);
+        } catch (...) {
+            delete s;
+            throw;
+        }
+        *out = s;
+        return PEDONI_OK;
+    });
+}
+
+int pedoni_simulator_save_checkpoint(PedoniSimulator* sim, const char* path)
+{
+    if (!sim || !path) return fail(PEDONI_E_INVALID, "null argument");
+    return guarded([&] {
+        sim->sim->save_checkpoint(path);
         return PEDONI_OK;
     });
 }

@@ -40,6 +40,7 @@ struct Args {                      // pedoni/src/args.rs:11-44
     int device = 0;
     std::string log_dir = "logs";
     bool fast_math = false;
+    std::string load_state, save_state;   // checkpoint files
 };
 
 void usage()
@@ -60,6 +61,8 @@ void usage()
               "      --device <N>             HIP device index [default: 0]\n"
               "      --log-dir <DIR>          Where the JSON log goes [default: logs]\n"
               "      --fast-math              PEDONI_MATH_FAST instead of bit-exact arithmetic\n"
+              "      --load-state <FILE>      Resume from a checkpoint instead of the scenario's initial spawns\n"
+              "      --save-state <FILE>      Write a checkpoint when the run ends\n"
               "  -h, --help                   Print help");
 }
 
@@ -93,6 +96,8 @@ Args parse(int argc, char** argv)
         else if (s == "--device") a.device = std::stoi(value(i, "--device"));
         else if (s == "--log-dir") a.log_dir = value(i, "--log-dir");
         else if (s == "--fast-math") a.fast_math = true;
+        else if (s == "--load-state") a.load_state = value(i, "--load-state");
+        else if (s == "--save-state") a.save_state = value(i, "--save-state");
         else if (!s.empty() && s[0] == '-') die("unexpected argument '" + s + "'");
         else if (!have_scenario) { a.scenario = s; have_scenario = true; }
         else die("unexpected argument '" + s + "'");
@@ -143,7 +148,10 @@ int main(int argc, char** argv)
     try {
         Scenario scenario = Scenario::from_toml(text.str());              // main.rs:55
         auto t_field = std::chrono::steady_clock::now();
-        Simulator simulator(to_simulator_options(args), scenario);         // main.rs:79
+        std::unique_ptr<Simulator> sim_owner =                             // main.rs:79
+            args.load_state.empty() ? std::make_unique<Simulator>(to_simulator_options(args), scenario)
+                                    : Simulator::resume(to_simulator_options(args), scenario, args.load_state);
+        Simulator& simulator = *sim_owner;
         const double time_new = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_field).count();
 
         std::signal(SIGINT, [](int) { g_sigint = true; });                 // main.rs:108
@@ -162,6 +170,12 @@ int main(int argc, char** argv)
             total_steps += 1;
             const auto spent = std::chrono::steady_clock::now() - start;
             if (spent < min_interval) std::this_thread::sleep_for(min_interval - spent); // main.rs:100-103
+        }
+
+        if (!args.save_state.empty()) {
+            simulator.save_checkpoint(args.save_state);
+            std::fprintf(stderr, "[INFO  pedoni] Saved checkpoint: %s (step %d)\n", args.save_state.c_str(),
+                         simulator.step);
         }
 
         mkdir(args.log_dir.c_str(), 0777);                                 // main.rs:119

@@ -156,6 +156,13 @@ public:
     int32_t step = 0;
 
     Simulator(SimulatorOptions options, Scenario scenario); // lib.rs:27-61
+    // build-owned checkpoint / resume (upstream has none, and its
+    // list_pedestrians drops velocity and desired speed).  The file holds the step counter,
+    // both generator states and the model's full SoA state in model order; a resumed run
+    // continues bit for bit like the uninterrupted one, spawns included.
+    void save_checkpoint(const std::string& path);
+    static std::unique_ptr<Simulator> resume(SimulatorOptions options, Scenario scenario,
+                                             const std::string& path);
     StepMetrics tick();                                     // lib.rs:64-100
     // build-owned: `n` ticks with the periodic spawners evaluated ON THE DEVICE (same two RNG
     // streams, so the crowd is bit-identical to n calls of tick()); no per-tick host work.
@@ -164,6 +171,9 @@ public:
     std::vector<Pedestrian> list_pedestrians() const { return model->list_pedestrians(); } // :102
 
 private:
+    struct ResumeTag {};
+    Simulator(SimulatorOptions options, Scenario scenario, ResumeTag); // no `once` spawns
+    void init_field_and_model();
     Rng rng_;
     bool device_spawners_ = false;
     void hand_spawning_to_device();

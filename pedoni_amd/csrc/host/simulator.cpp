@@ -4,6 +4,8 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstring>
 #include <stdexcept>
 
 namespace pedoni_host {
@@ -114,8 +116,7 @@ int32_t SocialForceModelHip::get_pedestrian_count() const
 }
 
 // ---- Simulator -------------------------------------------------------------------------------
-Simulator::Simulator(SimulatorOptions options_, Scenario scenario_)
-    : options(options_), scenario(std::move(scenario_))
+void Simulator::init_field_and_model()
 {
     rng_.state = options.seed;
     for (const PedestrianConfig& p : scenario.pedestrians)
@@ -135,7 +136,12 @@ Simulator::Simulator(SimulatorOptions options_, Scenario scenario_)
         throw std::runtime_error("Backend::Gpu (the reference's OpenCL model) is not part of "
                                  "this build; use Backend::Hip");
     }
+}
 
+Simulator::Simulator(SimulatorOptions options_, Scenario scenario_)
+    : options(options_), scenario(std::move(scenario_))
+{
+    init_field_and_model();
     std::vector<Pedestrian> new_pedestrians;                                // lib.rs:37-51
     for (const PedestrianConfig& p : scenario.pedestrians) {
         if (p.spawn.kind != PedestrianSpawnConfig::Once) continue;
@@ -144,6 +150,122 @@ Simulator::Simulator(SimulatorOptions options_, Scenario scenario_)
             new_pedestrians.push_back(Pedestrian{lerp(p1, p2, rng_.f32()), p.destination});
     }
     model->spawn_pedestrians(field, std::move(new_pedestrians));           // lib.rs:52
+}
+
+Simulator::Simulator(SimulatorOptions options_, Scenario scenario_, ResumeTag)
+    : options(options_), scenario(std::move(scenario_))
+{
+    init_field_and_model();
+}
+
+// ---- checkpoint / resume (build-owned) ---------------------------------------------------------
+namespace {
+
+constexpr char CKPT_MAGIC[8] = {'P', 'E', 'D', 'O', 'N', 'I', 'C', 'K'};
+constexpr uint32_t CKPT_VERSION = 1;
+
+struct CheckpointHeader {          // little-endian, 80 bytes, followed by the four arrays
+    char magic[8];
+    uint32_t version;
+    int32_t step;
+    uint64_t n_agents;
+    uint64_t rng_position, rng_speed;
+    float size_x, size_y, neighbor_grid_unit, field_grid_unit;
+    uint32_t n_waypoints, n_obstacles;
+    uint32_t use_neighbor_grid, use_distance_map;
+    uint32_t math_mode, reserved;
+};
+static_assert(sizeof(CheckpointHeader) == 80, "checkpoint header layout");
+
+} // namespace
+
+void Simulator::save_checkpoint(const std::string& path)
+{
+    auto* hip = dynamic_cast<SocialForceModelHip*>(model.get());
+    if (!hip) throw std::runtime_error("Simulator::save_checkpoint needs the Hip backend");
+    take_spawning_back();   // both generator states back on the host side of the boundary
+    CheckpointHeader h{};
+    std::memcpy(h.magic, CKPT_MAGIC, sizeof h.magic);
+    h.version = CKPT_VERSION;
+    h.step = step;
+    h.rng_position = rng_.state;
+    check(pedoni_hip_get_spawn_rng(hip->handle(), nullptr, &h.rng_speed), "save_checkpoint");
+    h.size_x = scenario.field.size.x;
+    h.size_y = scenario.field.size.y;
+    h.neighbor_grid_unit = options.neighbor_grid_unit;
+    h.field_grid_unit = options.field_grid_unit;
+    h.n_waypoints = (uint32_t)scenario.waypoints.size();
+    h.n_obstacles = (uint32_t)scenario.obstacles.size();
+    h.use_neighbor_grid = options.use_neighbor_grid;
+    h.use_distance_map = options.use_distance_map;
+    h.math_mode = (uint32_t)options.math_mode;
+
+    uint32_t n = 0;
+    check(pedoni_hip_download(hip->handle(), nullptr, nullptr, nullptr, nullptr, 0, &n), "save_checkpoint");
+    std::vector<float> pos(2 * (size_t)n), vel(2 * (size_t)n), v0(n);
+    std::vector<uint32_t> dest(n);
+    check(pedoni_hip_download(hip->handle(), pos.data(), dest.data(), vel.data(), v0.data(), n, &n),
+          "save_checkpoint");
+    h.n_agents = n;
+
+    const std::string tmp = path + ".part";   // never leave a half-written checkpoint behind
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) throw std::runtime_error("save_checkpoint: cannot create '" + tmp + "'");
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+    ok = ok && (n == 0 || (std::fwrite(pos.data(), sizeof(float), pos.size(), f) == pos.size() &&
+                           std::fwrite(vel.data(), sizeof(float), vel.size(), f) == vel.size() &&
+                           std::fwrite(v0.data(), sizeof(float), v0.size(), f) == v0.size() &&
+                           std::fwrite(dest.data(), sizeof(uint32_t), dest.size(), f) == dest.size()));
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) {
+        std::remove(tmp.c_str());
+        throw std::runtime_error("save_checkpoint: cannot write '" + path + "'");
+    }
+}
+
+std::unique_ptr<Simulator> Simulator::resume(SimulatorOptions options_, Scenario scenario_,
+                                             const std::string& path)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("Simulator::resume: cannot read '" + path + "'");
+    struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
+    CheckpointHeader h{};
+    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, CKPT_MAGIC, sizeof h.magic) != 0)
+        throw std::runtime_error("Simulator::resume: '" + path + "' is not a pedoni checkpoint");
+    if (h.version != CKPT_VERSION)
+        throw std::runtime_error("Simulator::resume: unsupported checkpoint version");
+    // the agents' state only means something in the world it was saved in
+    if (h.size_x != scenario_.field.size.x || h.size_y != scenario_.field.size.y ||
+        h.n_waypoints != scenario_.waypoints.size() || h.n_obstacles != scenario_.obstacles.size() ||
+        h.neighbor_grid_unit != options_.neighbor_grid_unit || h.field_grid_unit != options_.field_grid_unit ||
+        h.use_neighbor_grid != (uint32_t)options_.use_neighbor_grid ||
+        h.use_distance_map != (uint32_t)options_.use_distance_map)
+        throw std::runtime_error("Simulator::resume: the checkpoint was saved with another scenario "
+                                 "or other simulator options");
+    if (h.n_agents > 0xfffffff0ull) throw std::runtime_error("Simulator::resume: corrupt agent count");
+    const size_t n = (size_t)h.n_agents;
+    std::vector<float> pos(2 * n), vel(2 * n), v0(n);
+    std::vector<uint32_t> dest(n);
+    if (n && (std::fread(pos.data(), sizeof(float), pos.size(), f) != pos.size() ||
+              std::fread(vel.data(), sizeof(float), vel.size(), f) != vel.size() ||
+              std::fread(v0.data(), sizeof(float), v0.size(), f) != v0.size() ||
+              std::fread(dest.data(), sizeof(uint32_t), dest.size(), f) != dest.size()))
+        throw std::runtime_error("Simulator::resume: '" + path + "' is truncated");
+
+    std::unique_ptr<Simulator> sim(new Simulator(options_, std::move(scenario_), ResumeTag{}));
+    auto* hip = dynamic_cast<SocialForceModelHip*>(sim->model.get());
+    if (!hip) throw std::runtime_error("Simulator::resume needs the Hip backend");
+    // model order = the order of the last sort pass: appended in that order, the next pass's
+    // stable sort reproduces the uninterrupted run's order
+    check(pedoni_hip_append(hip->handle(), pos.data(), dest.data(), v0.data(), vel.data(), (uint32_t)n),
+          "Simulator::resume");
+    // bin them now (the pass the next tick runs anyway: a second pass over unmoved agents
+    // changes nothing), so that either tick() or tick_n() may follow
+    check(pedoni_hip_sort_despawn(hip->handle()), "Simulator::resume");
+    check(pedoni_hip_set_speed_rng(hip->handle(), h.rng_speed), "Simulator::resume");
+    sim->rng_.state = h.rng_position;
+    sim->step = h.step;
+    return sim;
 }
 
 void Simulator::hand_spawning_to_device()

@@ -903,6 +903,16 @@ int pedoni_hip_get_spawn_rng(PedoniModel* m, uint64_t* position_rng_state, uint6
     return PEDONI_OK;
 }
 
+int pedoni_hip_set_speed_rng(PedoniModel* m, uint64_t speed_rng_state)
+{
+    TRY(bind(m));
+    if (m->n_spawners)
+        return fail(PEDONI_E_INVALID, "set_speed_rng: uninstall the device spawners first "
+                                      "(they own the stream while installed)");
+    m->rng.s = speed_rng_state;
+    return PEDONI_OK;
+}
+
 int pedoni_hip_tick(PedoniModel* m, PedoniStepMetrics* metrics)
 {
     TRY(bind(m));

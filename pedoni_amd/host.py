@@ -24,6 +24,7 @@ SYMBOLS = [
     "pedoni_field_potential_map", "pedoni_field_obstacle_exist", "pedoni_field_get_potential",
     "pedoni_field_get_obstacle_distance", "pedoni_simulator_new", "pedoni_simulator_free",
     "pedoni_simulator_tick", "pedoni_simulator_tick_n", "pedoni_simulator_step", "pedoni_simulator_list_pedestrians",
+    "pedoni_simulator_save_checkpoint", "pedoni_simulator_resume",
     "pedoni_simulator_model", "pedoni_simulator_field",
 ]
 
@@ -222,13 +223,27 @@ class Field:
 class Simulator:
     """lib.rs:17-105 `Simulator` (new / tick / list_pedestrians, field `step`)."""
 
-    def __init__(self, options: SimulatorOptions, scenario: Scenario):
+    def __init__(self, options: SimulatorOptions, scenario: Scenario, _resume_from=None):
         self._lib = load_library()
         self._h = C.c_void_p(None)
         self.options = options
         self.scenario = scenario
         opt = options._c()
-        _check(self._lib.pedoni_simulator_new(C.byref(opt), scenario._h, C.byref(self._h)))
+        if _resume_from is None:
+            _check(self._lib.pedoni_simulator_new(C.byref(opt), scenario._h, C.byref(self._h)))
+        else:
+            _check(self._lib.pedoni_simulator_resume(C.byref(opt), scenario._h,
+                                                     str(_resume_from).encode(), C.byref(self._h)))
+
+    @classmethod
+    def resume(cls, options: SimulatorOptions, scenario: Scenario, path) -> "Simulator":
+        """Continue from a file written by `save_checkpoint` (build-owned; upstream has no
+        checkpointing): same step counter, generator states and full agent state, so the run
+        goes on bit for bit like the uninterrupted one."""
+        return cls(options, scenario, _resume_from=path)
+
+    def save_checkpoint(self, path) -> None:
+        _check(self._lib.pedoni_simulator_save_checkpoint(self._h, str(path).encode()))
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -48,6 +48,25 @@ def test_cli_headless_run_writes_the_diagnostic_log(tmp_path):
     assert d["preprocess_metrics"]["time_calc_field"] > 0
 
 
+@pytest.mark.gpu
+def test_cli_save_and_load_state_continue_the_run(tmp_path):
+    """--save-state / --load-state (build-owned): 61 ticks, checkpoint, 40 more ticks must show
+    the same crowd sizes as one run of 101 ticks."""
+    common = ("-H", "-s", "1000000", "--seed", "9", SCENARIO)
+    one, two_a, two_b = tmp_path / "one", tmp_path / "two_a", tmp_path / "two_b"
+    r = run("--max-steps", "100", "--log-dir", one, *common)
+    assert r.returncode == 0, r.stderr
+    r = run("--max-steps", "60", "--log-dir", two_a, "--save-state", tmp_path / "s.ckpt", *common)
+    assert r.returncode == 0 and "Saved checkpoint" in r.stderr, r.stderr
+    r = run("--max-steps", "39", "--log-dir", two_b, "--load-state", tmp_path / "s.ckpt", *common)
+    assert r.returncode == 0, r.stderr
+    counts = lambda d: json.loads(next(d.glob("*_log.json")).read_text())["step_metrics"]["active_ped_count"]
+    whole = counts(one)
+    assert len(whole) == 101 and counts(two_a) + counts(two_b) == whole
+    r = run("--max-steps", "5", "--log-dir", two_b, "--load-state", tmp_path / "missing.ckpt", *common)
+    assert r.returncode != 0 and "cannot read" in r.stderr
+
+
 def _build_c_demo(tmp_path):
     exe = tmp_path / "c_abi_demo"
     lib = ROOT / "pedoni_amd" / "lib"

@@ -200,3 +200,50 @@ def test_device_spawning_equals_host_spawning(hip):
         assert bit_equal(po, pa).all()
     for s in (a, b, c):
         s.close()
+
+
+def test_checkpoint_resume_continues_bit_for_bit(hip, tmp_path):
+    """Build-owned checkpoint (upstream has none and list_pedestrians drops velocity
+    and desired speed): step counter, both generator states, full SoA state.  A run resumed
+    from the file -- in a fresh Simulator -- must continue exactly like the uninterrupted
+    one, Poisson arrivals and desired-speed draws included, whether the checkpoint is taken
+    after host ticks or after a device-spawning batch."""
+    from pedoni_amd import abi, host
+    sc = host.Scenario(SPAWN_SCENARIO)
+    opt = host.SimulatorOptions(seed=11)
+    ref = host.Simulator(opt, sc)
+    for _ in range(90):
+        ref.tick()
+    want_pos, want_dest = _snapshot(ref)
+
+    a = host.Simulator(opt, sc)
+    for _ in range(25):
+        a.tick()
+    a.save_checkpoint(tmp_path / "t25.ckpt")
+    a.close()
+    b = host.Simulator.resume(opt, sc, tmp_path / "t25.ckpt")
+    assert b.step == 25
+    b.tick_n(35)                                   # device-side spawning after the resume
+    b.save_checkpoint(tmp_path / "t60.ckpt")       # ... and a checkpoint taken right after it
+    b.close()
+    c = host.Simulator.resume(opt, sc, tmp_path / "t60.ckpt")
+    assert c.step == 60
+    for _ in range(30):
+        c.tick()
+    got_pos, got_dest = _snapshot(c)
+    assert c.step == ref.step == 90
+    assert len(got_pos) == len(want_pos) > 300 and np.array_equal(got_dest, want_dest)
+    assert bit_equal(got_pos, want_pos).all()
+    c.close()
+    ref.close()
+
+    # the world must match: other options or another scenario are refused
+    with pytest.raises(abi.PedoniError, match="another scenario or other simulator options"):
+        host.Simulator.resume(host.SimulatorOptions(seed=11, neighbor_grid_unit=2.0), sc, tmp_path / "t60.ckpt")
+    (tmp_path / "junk.ckpt").write_bytes(b"not a checkpoint at all")
+    with pytest.raises(abi.PedoniError, match="not a pedoni checkpoint"):
+        host.Simulator.resume(opt, sc, tmp_path / "junk.ckpt")
+    blob = (tmp_path / "t60.ckpt").read_bytes()
+    (tmp_path / "cut.ckpt").write_bytes(blob[: len(blob) // 2])
+    with pytest.raises(abi.PedoniError, match="truncated"):
+        host.Simulator.resume(opt, sc, tmp_path / "cut.ckpt")
