@@ -176,6 +176,8 @@ def main() -> None:
                     help="skip the per-kernel hipEvent pairs in the timed region")
     args = ap.parse_args()
 
+    # the host driver of this pool only supports dmabuf IPC (RCCL / cross-process tensors)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # RCCL prints a version banner on stdout: keep fd 1 for the ONE JSON line
     json_fd = os.dup(1)
     os.dup2(2, 1)
