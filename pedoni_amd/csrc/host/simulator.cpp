@@ -303,6 +303,17 @@ StepMetrics Simulator::tick_n(uint32_t n)
     using clk = std::chrono::steady_clock;
     auto* hip = dynamic_cast<SocialForceModelHip*>(model.get());
     if (!hip) throw std::runtime_error("Simulator::tick_n needs the Hip backend");
+    if (!options.use_neighbor_grid) {
+        // the brute-force option path (sfm.rs:78-88,157-185) keeps spawning on the host
+        StepMetrics total;
+        for (uint32_t k = 0; k < n; ++k) {
+            StepMetrics m = tick();
+            total.active_ped_count = m.active_ped_count;
+            total.time_spawn += m.time_spawn;
+            total.time_calc_state += m.time_calc_state;
+        }
+        return total;
+    }
     if (!device_spawners_) hand_spawning_to_device();
     const auto t0 = clk::now();
     check(pedoni_hip_tick_n(hip->handle(), n), "Simulator::tick_n");

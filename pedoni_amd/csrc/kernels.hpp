@@ -389,12 +389,17 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
                              GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
                              const uint32_t* __restrict__ cs_new, SortFlags* __restrict__ flags,
                              uint32_t parity, uint32_t* __restrict__ cell_count, SoA a,
-                             uint32_t* __restrict__ slots)
+                             uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed)
 {
     uint32_t j = i0 + xcd_contiguous_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     // the NEXT tick's flag is raised by this tick's update_states and the next K_KEY; it can
     // be cleared here because every key of this tick has been written and nothing reads it now
-    if (blockIdx.x == 0 && threadIdx.x == 0) flags->far[parity ^ 1u] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        flags->far[parity ^ 1u] = 0;
+        // the agents stored by the device since the last pass (exchanged lists, device spawns)
+        // have their keys: mark them consumed
+        if (halo_consumed) halo_consumed->n_below = halo_consumed->n_above = halo_consumed->counted = 0;
+    }
     if (j >= n_total) return;
     uint32_t c = key[j];
     if (c == DEAD) return;

@@ -380,7 +380,8 @@ int sort_despawn(PedoniModel* m)
             if (t.rc) return t.rc;
             hipLaunchKernelGGL(place_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
-                               m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots);
+                               m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
+                               (m->halo_cap || m->n_spawners) ? m->d_halo : nullptr);
         }
         {
             Timed t(m, PEDONI_K_REORDER);
@@ -420,8 +421,7 @@ int sort_despawn(PedoniModel* m)
     m->pv = dst;
     m->vd = vdst;
     m->gap_end = m->n_upper; // every stored agent is now either live (< *d_live) or stale
-    if (m->halo_cap || m->n_spawners) // the device-stored agents are consumed
-        HIP_TRY(hipMemsetAsync(m->d_halo, 0, 3 * sizeof(uint32_t), m->stream));
+    // (the device-stored agents are marked consumed by place_kernel; the no-grid path has none)
     m->sorted = true;
     return PEDONI_OK;
 }
@@ -863,6 +863,9 @@ int pedoni_hip_set_spawners(PedoniModel* m, const PedoniSpawner* spawners, uint3
     if (n && !spawners) return fail(PEDONI_E_INVALID, "set_spawners: null spawners");
     if (m->halo_cap) return fail(PEDONI_E_INVALID, "set_spawners: not supported for a band of a sharded run");
     if (n && max_per_tick == 0) return fail(PEDONI_E_INVALID, "set_spawners: max_per_tick must be > 0");
+    if (n && !m->opt.use_neighbor_grid)
+        return fail(PEDONI_E_INVALID, "set_spawners: device spawning needs the neighbor grid "
+                                      "(the brute-force option path spawns on the host)");
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (m->n_spawners) { // hand the desired-speed stream back to the host side
         SpawnState st{};

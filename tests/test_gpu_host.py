@@ -247,3 +247,22 @@ def test_checkpoint_resume_continues_bit_for_bit(hip, tmp_path):
     (tmp_path / "cut.ckpt").write_bytes(blob[: len(blob) // 2])
     with pytest.raises(abi.PedoniError, match="truncated"):
         host.Simulator.resume(opt, sc, tmp_path / "cut.ckpt")
+
+
+def test_tick_n_without_neighbor_grid_spawns_on_the_host(hip):
+    """Device spawning is a neighbor-grid feature; with `use_neighbor_grid = false` (the
+    reference's brute-force option, sfm.rs:78-88,157-185) tick_n must fall back to per-tick
+    host spawning and still equal tick() x n."""
+    from pedoni_amd import host
+    sc = host.Scenario(SPAWN_SCENARIO)
+    opt = host.SimulatorOptions(seed=21, use_neighbor_grid=False)
+    a, b = host.Simulator(opt, sc), host.Simulator(opt, sc)
+    for _ in range(40):
+        a.tick()
+    m = b.tick_n(40)
+    pa, da = _snapshot(a)
+    pb, db = _snapshot(b)
+    assert a.step == b.step == 40 and m["active_ped_count"] == len(pa) == len(pb) > 100
+    assert np.array_equal(da, db) and bit_equal(pa, pb).all()
+    a.close()
+    b.close()
