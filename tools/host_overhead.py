@@ -19,7 +19,8 @@ for overlap in (True, False):
     pos, dest, v0, vel = bench.uniform_crowd(1_000_000, (12, L - 12), (2, L - 2), 12345)
     r.load(pos, dest, v0, vel)
     r.tick_n(10); torch.cuda.synchronize()
-    t0 = time.perf_counter(); r.tick_n(200); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-    print(f"overlap={overlap}: host submit {1e6*(t1-t0)/200:.1f} us/tick, total {1e6*(t2-t0)/200:.1f} us/tick", flush=True)
+    for n in (200, 20):
+        t0 = time.perf_counter(); r.tick_n(n); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        print(f"overlap={overlap} n={n}: host submit {1e6*(t1-t0)/n:.1f} us/tick, total {1e6*(t2-t0)/n:.1f} us/tick", flush=True)
     model.close()
 dist.destroy_process_group()
