@@ -218,6 +218,11 @@ int pedoni_hip_owned_count(PedoniModel* m, int32_t* count);
  * force's unscaled division core -- equal to a/b wherever pair_force_hot uses it) */
 int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mode, const float* a,
                              const float* b, float* out, uint32_t n);
+/* [ext] the same for the pair force (sfm.rs:130-153) of n independent (agent, neighbour)
+ * pairs: acc_xy (in/out) += force on an agent at pos_xy with goal direction e_xy from a
+ * neighbour at pos_i_xy moving with vel_i_xy -- the device function both force kernels call */
+int pedoni_hip_selftest_pair(int device, int32_t math_mode, const float* pos_xy, const float* e_xy,
+                             const float* pos_i_xy, const float* vel_i_xy, float* acc_xy, uint32_t n);
 
 #ifdef __cplusplus
 }

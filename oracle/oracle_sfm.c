@@ -300,6 +300,19 @@ static ovec2 acceleration_of(const oracle_model* m, const oracle_field* f,
     return acc;
 }
 
+/* test hook: sfm.rs:130-153 for n independent (agent, neighbour) pairs; acc_xy is in/out */
+void oracle_pair_forces(const float* pos_xy, const float* e_xy, const float* pos_i_xy,
+                        const float* vel_i_xy, float* acc_xy, uint32_t n)
+{
+    for (uint32_t k = 0; k < n; ++k) {
+        ovec2 acc = ov(acc_xy[2 * k], acc_xy[2 * k + 1]);
+        pair_force(ov(pos_xy[2 * k], pos_xy[2 * k + 1]), ov(e_xy[2 * k], e_xy[2 * k + 1]),
+                   ov(pos_i_xy[2 * k], pos_i_xy[2 * k + 1]), ov(vel_i_xy[2 * k], vel_i_xy[2 * k + 1]), &acc);
+        acc_xy[2 * k] = acc.x;
+        acc_xy[2 * k + 1] = acc.y;
+    }
+}
+
 void oracle_calc_accelerations(const oracle_model* m, const oracle_field* f,
                                const oracle_segment* obstacles, uint32_t n_obstacles,
                                float* acc_xy)

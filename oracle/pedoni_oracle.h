@@ -107,6 +107,9 @@ void oracle_spawn_pedestrians(oracle_model* m, const oracle_field* f,
 void oracle_update_states(oracle_model* m, const oracle_field* f,
                           const oracle_segment* obstacles, uint32_t n_obstacles);
 /* sfm.rs:93-241 only (accelerations, no integration) */
+/* test hook: the pair force of sfm.rs:130-153 for n independent pairs (acc_xy in/out) */
+void oracle_pair_forces(const float* pos_xy, const float* e_xy, const float* pos_i_xy,
+                        const float* vel_i_xy, float* acc_xy, uint32_t n);
 void oracle_calc_accelerations(const oracle_model* m, const oracle_field* f,
                                const oracle_segment* obstacles, uint32_t n_obstacles,
                                float* acc_xy);

@@ -213,6 +213,15 @@ def rasterize_outline(verts_cells, rows: int, cols: int) -> np.ndarray:
 
 
 # ---- models/sfm.rs ----------------------------------------------------------------------
+def pair_forces(pos, e, pos_i, vel_i, acc=None) -> np.ndarray:
+    """sfm.rs:130-153 for n independent (agent, neighbour) pairs: acc + force (or acc when the
+    neighbour is beyond the 2 m cutoff)."""
+    pos, e, pos_i, vel_i = (np.ascontiguousarray(a, np.float32).reshape(-1, 2) for a in (pos, e, pos_i, vel_i))
+    out = np.zeros_like(pos) if acc is None else np.ascontiguousarray(acc, np.float32).reshape(-1, 2).copy()
+    lib().oracle_pair_forces(_fp(pos), _fp(e), _fp(pos_i), _fp(vel_i), _fp(out), C.c_uint32(len(pos)))
+    return out
+
+
 class OracleModel:
     """SocialForceModel (models/sfm.rs) restated on the CPU."""
 

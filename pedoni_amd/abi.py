@@ -38,7 +38,7 @@ SYMBOLS = [
     "pedoni_hip_halo_pack", "pedoni_hip_halo_unpack", "pedoni_hip_halo_tick",
     "pedoni_hip_halo_tick_begin", "pedoni_hip_halo_tick_end",
     "pedoni_hip_owned_count",
-    "pedoni_hip_selftest_math", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
+    "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
 ]
 
 
@@ -151,6 +151,17 @@ def selftest_math(op: int, a, b=None, math_mode: int = MATH_EXACT, device: int =
     _check(lib, lib.pedoni_hip_selftest_math(
         C.c_int(device), C.c_int32(op), C.c_int32(math_mode), _ptr(a, C.c_float),
         _ptr(bb, C.c_float), _ptr(out, C.c_float), C.c_uint32(a.size)))
+    return out
+
+
+def selftest_pair(pos, e, pos_i, vel_i, acc=None, math_mode: int = MATH_EXACT, device: int = 0) -> np.ndarray:
+    """acc + pair force (sfm.rs:130-153) of n independent pairs, evaluated on the device."""
+    lib = load_library()
+    pos, e, pos_i, vel_i = (_f32(a).reshape(-1, 2) for a in (pos, e, pos_i, vel_i))
+    out = np.zeros_like(pos) if acc is None else _f32(acc).reshape(-1, 2).copy()
+    _check(lib, lib.pedoni_hip_selftest_pair(
+        C.c_int(device), C.c_int32(math_mode), _ptr(pos, C.c_float), _ptr(e, C.c_float),
+        _ptr(pos_i, C.c_float), _ptr(vel_i, C.c_float), _ptr(out, C.c_float), C.c_uint32(len(pos))))
     return out
 
 

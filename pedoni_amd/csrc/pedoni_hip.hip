@@ -1300,7 +1300,53 @@ __global__ void selftest_kernel(int op, const float* a, const float* b, float* o
     }
     out[i] = r;
 }
+template <int MODE>
+__global__ void selftest_pair_kernel(const float2* pos, const float2* e, const float2* pos_i,
+                                     const float2* vel_i, float2* acc, uint32_t n)
+{
+    __shared__ uint64_t tab[32];
+    if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    v2 a = mk(acc[i].x, acc[i].y);
+    pair_force<MODE>(mk(pos[i].x, pos[i].y), mk(e[i].x, e[i].y), mk(pos_i[i].x, pos_i[i].y),
+                     mk(vel_i[i].x, vel_i[i].y), a, tab);
+    acc[i] = make_float2(a.x, a.y);
+}
 } // namespace
+
+extern "C" int pedoni_hip_selftest_pair(int device, int32_t math_mode, const float* pos_xy,
+                                        const float* e_xy, const float* pos_i_xy,
+                                        const float* vel_i_xy, float* acc_xy, uint32_t n)
+{
+    if (!pos_xy || !e_xy || !pos_i_xy || !vel_i_xy || !acc_xy)
+        return fail(PEDONI_E_INVALID, "selftest_pair: null argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return fail(PEDONI_E_NO_DEVICE, "selftest: no HIP device");
+    HIP_TRY(hipSetDevice(device));
+    if (n == 0) return PEDONI_OK;
+    float2* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const float* h[5] = {pos_xy, e_xy, pos_i_xy, vel_i_xy, acc_xy};
+    int rc = PEDONI_OK;
+    for (int k = 0; k < 5 && rc == PEDONI_OK; ++k) {
+        if (hipMalloc((void**)&d[k], (size_t)n * sizeof(float2)) != hipSuccess ||
+            hipMemcpy(d[k], h[k], (size_t)n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(PEDONI_E_HIP, "selftest_pair: device allocation / copy failed");
+    }
+    if (rc == PEDONI_OK) {
+        if (math_mode == PEDONI_MATH_FAST)
+            hipLaunchKernelGGL(selftest_pair_kernel<1>, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], d[1], d[2], d[3], d[4], n);
+        else
+            hipLaunchKernelGGL(selftest_pair_kernel<0>, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], d[1], d[2], d[3], d[4], n);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpy(acc_xy, d[4], (size_t)n * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(PEDONI_E_HIP, "selftest_pair: launch / copy failed");
+    }
+    for (int k = 0; k < 5; ++k) hipFree(d[k]);
+    return rc;
+}
 
 extern "C" int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mode, const float* a,
                                         const float* b, float* out, uint32_t n)

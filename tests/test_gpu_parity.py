@@ -287,6 +287,70 @@ def test_coincident_agents_go_nan_then_despawn(hip, oracle):
     gpu.close()
 
 
+def _pair_fuzz_cases(rng, n):
+    """(pos, e, pos_i, vel_i) spanning the hot form's domain, its edges and well beyond."""
+    def logu(lo, hi, size):
+        return (np.exp2(rng.uniform(lo, hi, size)) * rng.choice([-1.0, 1.0], size)).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    e = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    # a crowd's ordinary pairs
+    pos = rng.uniform(1, 200, (n, 2)).astype(np.float32)
+    pos_i = (pos + rng.uniform(-2.2, 2.2, (n, 2))).astype(np.float32)
+    vel = rng.normal(0, 1.2, (n, 2)).astype(np.float32)
+    k = n // 8
+    # velocities over 90 binades, exact zeros, overflowing squares, infinities
+    vel[:k] = logu(-70, 22, (k, 2))
+    vel[k:k + k // 4] = 0.0
+    vel[k + k // 4:k + k // 2] = logu(60, 66, (k // 4, 2))
+    vel[k + k // 2:k + k // 2 + 8] = np.inf
+    # separations over 120 binades around the origin (squares denormal or zero)
+    a, b = 2 * k, 3 * k
+    pos[a:b] = logu(-80, -20, (k, 2))
+    pos_i[a:b] = pos[a:b] + logu(-80, 1, (k, 2))
+    # the neighbour's next step lands on the agent: t1 -> 0, t2^2 - (|v| dt)^2 cancels
+    a, b = 3 * k, 4 * k
+    d = (pos[a:b] - pos_i[a:b]).astype(np.float32)
+    vel[a:b] = (d * np.float32(10.0) * (1 + rng.uniform(-1, 1, (k, 1)) * np.exp2(rng.uniform(-24, -2, (k, 1))))).astype(np.float32)
+    # axis-aligned pairs (a zero numerator in every division by a length)
+    a, b = 4 * k, 4 * k + k // 2
+    pos_i[a:b, 0] = pos[a:b, 0]
+    vel[a:b, 0] = 0.0
+    # b near 26 (x / 0.3 near the exp cut-off) and beyond
+    a, b = 5 * k, 6 * k
+    vel[a:b] = logu(7, 10, (k, 2))
+    # NaN goal direction (an agent on a flat potential), NaN neighbour
+    e[6 * k:6 * k + 16] = np.nan
+    pos_i[6 * k + 16:6 * k + 32] = np.nan
+    return pos, e, pos_i, vel
+
+
+def test_pair_force_fuzz_hot_and_generic_forms_match_the_oracle(hip, oracle):
+    """sfm.rs:130-153 pair by pair, 2 M random pairs including every edge of the hot form's
+    validity range (device_math.hpp pair_force_hot): the device function both force kernels
+    call must equal the oracle bit for bit, whichever form evaluates the pair."""
+    from pedoni_amd import abi
+    rng = np.random.default_rng(2718)
+    pos, e, pos_i, vel = _pair_fuzz_cases(rng, 2_000_000)
+    acc0 = rng.normal(0, 3, pos.shape).astype(np.float32)
+    with np.errstate(all="ignore"):
+        want = oracle.pair_forces(pos, e, pos_i, vel, acc0)
+        got = abi.selftest_pair(pos, e, pos_i, vel, acc0)
+    eq = bit_equal(got, want).all(axis=1)
+    bad = np.flatnonzero(~eq)
+    assert len(bad) == 0, (f"{len(bad)} pairs differ, e.g. #{bad[0]}: pos {pos[bad[0]]} pos_i {pos_i[bad[0]]} "
+                           f"vel {vel[bad[0]]} e {e[bad[0]]}: {got[bad[0]]} != {want[bad[0]]}")
+    # the fuzz did reach both forms: plenty of finite forces, and NaN / untouched ones
+    changed = ~bit_equal(want, acc0).all(axis=1)
+    assert changed.sum() > 500_000 and np.isnan(want).any() and (~changed).sum() > 10_000
+    # fast mode on the ordinary pairs: within its budget
+    sl = slice(7 * (len(pos) // 8), None)
+    fast = abi.selftest_pair(pos[sl], e[sl], pos_i[sl], vel[sl], acc0[sl], math_mode=abi.MATH_FAST)
+    f_ref = want[sl].astype(np.float64) - acc0[sl]
+    err = np.linalg.norm(fast.astype(np.float64) - want[sl], axis=1)
+    ok = err <= 2e-5 * np.maximum(np.linalg.norm(f_ref, axis=1), 1e-3) + 1e-6 * np.linalg.norm(acc0[sl], axis=1)
+    assert ok.all(), f"{(~ok).sum()} fast-mode pairs outside budget"
+
+
 def test_pair_force_outside_the_hot_range_takes_the_generic_path(hip, oracle):
     """The exact pair force has a hot form valid for sqrt arguments in [2^-96, inf) and b < 26
     (device_math.hpp pair_force_hot) and a generic form for everything else.  Neighbours
