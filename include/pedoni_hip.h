@@ -221,6 +221,11 @@ int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mode, const fl
 /* [ext] the same for the pair force (sfm.rs:130-153) of n independent (agent, neighbour)
  * pairs: acc_xy (in/out) += force on an agent at pos_xy with goal direction e_xy from a
  * neighbour at pos_i_xy moving with vel_i_xy -- the device function both force kernels call */
+/* [ext] the field stencil: sobel_filter and the bilinear centre sample (util.rs:44-75) of a
+ * rows x cols map at n grid-coordinate points, by the shared-patch device form */
+int pedoni_hip_selftest_field(int device, const float* grid, uint32_t rows, uint32_t cols,
+                              const float* px, const float* py, float* grad_xy, float* centre,
+                              uint32_t n);
 int pedoni_hip_selftest_pair(int device, int32_t math_mode, const float* pos_xy, const float* e_xy,
                              const float* pos_i_xy, const float* vel_i_xy, float* acc_xy, uint32_t n);
 

@@ -51,6 +51,16 @@ void oracle_sobel_filter(const float* grid, int32_t rows, int32_t cols, float px
     out_xy[1] = u00 + u01 + u01 + u02 - u20 - u21 - u21 - u22; /* :73 */
 }
 
+/* test hook: sobel_filter + bilinear (util.rs:44-75) at n grid-coordinate points */
+void oracle_sample_many(const float* grid, int32_t rows, int32_t cols, const float* px,
+                        const float* py, float* grad_xy, float* centre, uint32_t n)
+{
+    for (uint32_t k = 0; k < n; ++k) {
+        oracle_sobel_filter(grid, rows, cols, px[k], py[k], grad_xy + 2 * k);
+        centre[k] = oracle_bilinear(grid, rows, cols, px[k], py[k]);
+    }
+}
+
 /* util.rs:92-103.  The degenerate branch really is `a - line[0]` upstream. */
 void oracle_distance_from_line(float px, float py, const float* l, float* out_xy)
 {

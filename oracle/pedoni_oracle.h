@@ -52,6 +52,9 @@ typedef struct oracle_model oracle_model;
 float oracle_bilinear(const float* grid, int32_t rows, int32_t cols, float px, float py);
 void oracle_sobel_filter(const float* grid, int32_t rows, int32_t cols, float px, float py,
                          float* out_xy);
+/* test hook: both of the above at n points */
+void oracle_sample_many(const float* grid, int32_t rows, int32_t cols, const float* px,
+                        const float* py, float* grad_xy, float* centre, uint32_t n);
 void oracle_distance_from_line(float px, float py, const float* line_xyxy, float* out_xy);
 void oracle_line_with_width(const float* line_xyxy, float width, float* out_4xy);
 int32_t oracle_poisson(uint64_t* rng_state, double lambda);

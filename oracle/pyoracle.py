@@ -96,6 +96,16 @@ def sobel_filter(grid: np.ndarray, px: float, py: float) -> np.ndarray:
     return out
 
 
+def sample_many(grid: np.ndarray, px, py):
+    """(sobel_filter, bilinear) of util.rs:44-75 at many grid-coordinate points."""
+    g = np.ascontiguousarray(grid, np.float32)
+    px, py = np.ascontiguousarray(px, np.float32), np.ascontiguousarray(py, np.float32)
+    grad, centre = np.zeros((len(px), 2), np.float32), np.zeros(len(px), np.float32)
+    lib().oracle_sample_many(_fp(g), g.shape[0], g.shape[1], _fp(px), _fp(py), _fp(grad), _fp(centre),
+                             C.c_uint32(len(px)))
+    return grad, centre
+
+
 def distance_from_line(point, line) -> np.ndarray:
     l = np.ascontiguousarray(line, np.float32).ravel()
     out = np.zeros(2, np.float32)

@@ -38,7 +38,7 @@ SYMBOLS = [
     "pedoni_hip_halo_pack", "pedoni_hip_halo_unpack", "pedoni_hip_halo_tick",
     "pedoni_hip_halo_tick_begin", "pedoni_hip_halo_tick_end",
     "pedoni_hip_owned_count",
-    "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
+    "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_selftest_field", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
 ]
 
 
@@ -152,6 +152,19 @@ def selftest_math(op: int, a, b=None, math_mode: int = MATH_EXACT, device: int =
         C.c_int(device), C.c_int32(op), C.c_int32(math_mode), _ptr(a, C.c_float),
         _ptr(bb, C.c_float), _ptr(out, C.c_float), C.c_uint32(a.size)))
     return out
+
+
+def selftest_field(grid, px, py, device: int = 0):
+    """(sobel_filter, bilinear centre) of a map at grid-coordinate points, on the device."""
+    lib = load_library()
+    g = _f32(grid)
+    px, py = _f32(px).ravel(), _f32(py).ravel()
+    grad, centre = np.zeros((len(px), 2), np.float32), np.zeros(len(px), np.float32)
+    _check(lib, lib.pedoni_hip_selftest_field(
+        C.c_int(device), _ptr(g, C.c_float), C.c_uint32(g.shape[0]), C.c_uint32(g.shape[1]),
+        _ptr(px, C.c_float), _ptr(py, C.c_float), _ptr(grad, C.c_float), _ptr(centre, C.c_float),
+        C.c_uint32(len(px))))
+    return grad, centre
 
 
 def selftest_pair(pos, e, pos_i, vel_i, acc=None, math_mode: int = MATH_EXACT, device: int = 0) -> np.ndarray:

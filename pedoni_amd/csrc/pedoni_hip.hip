@@ -1314,7 +1314,54 @@ __global__ void selftest_pair_kernel(const float2* pos, const float2* e, const f
                      mk(vel_i[i].x, vel_i[i].y), a, tab);
     acc[i] = make_float2(a.x, a.y);
 }
+__global__ void selftest_field_kernel(const float* grid, int32_t rows, int32_t cols, const float* px,
+                                      const float* py, float2* grad, float* centre, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float c;
+    v2 g = sobel_fast(grid, rows, cols, px[i], py[i], &c);
+    grad[i] = make_float2(g.x, g.y);
+    centre[i] = c;
+}
 } // namespace
+
+extern "C" int pedoni_hip_selftest_field(int device, const float* grid, uint32_t rows, uint32_t cols,
+                                         const float* px, const float* py, float* grad_xy,
+                                         float* centre, uint32_t n)
+{
+    if (!grid || !px || !py || !grad_xy || !centre || rows == 0 || cols == 0 ||
+        rows > 0x7fffffffu || cols > 0x7fffffffu)
+        return fail(PEDONI_E_INVALID, "selftest_field: bad argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return fail(PEDONI_E_NO_DEVICE, "selftest: no HIP device");
+    HIP_TRY(hipSetDevice(device));
+    if (n == 0) return PEDONI_OK;
+    float *dg = nullptr, *dx = nullptr, *dy = nullptr, *dc = nullptr;
+    float2* dgrad = nullptr;
+    const size_t cells = (size_t)rows * cols;
+    int rc = PEDONI_OK;
+    if (hipMalloc((void**)&dg, cells * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&dx, n * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&dy, n * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&dc, n * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&dgrad, n * sizeof(float2)) != hipSuccess ||
+        hipMemcpy(dg, grid, cells * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dx, px, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dy, py, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(PEDONI_E_HIP, "selftest_field: device allocation / copy failed");
+    if (rc == PEDONI_OK) {
+        hipLaunchKernelGGL(selftest_field_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, dg, (int32_t)rows,
+                           (int32_t)cols, dx, dy, dgrad, dc, n);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpy(grad_xy, dgrad, n * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(centre, dc, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(PEDONI_E_HIP, "selftest_field: launch / copy failed");
+    }
+    hipFree(dg); hipFree(dx); hipFree(dy); hipFree(dc); hipFree(dgrad);
+    return rc;
+}
 
 extern "C" int pedoni_hip_selftest_pair(int device, int32_t math_mode, const float* pos_xy,
                                         const float* e_xy, const float* pos_i_xy,

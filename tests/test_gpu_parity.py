@@ -324,6 +324,42 @@ def _pair_fuzz_cases(rng, n):
     return pos, e, pos_i, vel
 
 
+def test_field_stencil_fuzz_patch_and_per_tap_forms(hip, oracle):
+    """sobel_filter + bilinear (util.rs:44-75): the device evaluates the 3 x 3 taps from one
+    4 x 4 texel patch and falls back to the literal per-tap form when rounding of p +- 1 moves
+    a tap off the patch.  Points just below / at / above integers, around the map's borders,
+    far outside, huge, negative, NaN and inf must all give the reference's bits."""
+    from pedoni_amd import abi
+    rng = np.random.default_rng(1618)
+    rows, cols = 57, 83
+    grid = rng.normal(0, 3, (rows, cols)).astype(np.float32)
+    grid[rng.random((rows, cols)) < 0.05] = 1e12          # obstacle-like texels
+    grid[5, 7], grid[6, 7] = np.float32(3.4028235e38), np.float32(1e24)
+    n = 300_000
+    px = rng.uniform(-6, cols + 6, n).astype(np.float32)
+    py = rng.uniform(-6, rows + 6, n).astype(np.float32)
+    k = n // 6
+    # within a few ulps of an integer: p + 1 and p - 1 round across it
+    ints = rng.integers(-3, cols + 3, k).astype(np.float32)
+    px[:k] = np.nextafter(ints, ints + rng.choice([-1, 1], k).astype(np.float32)).astype(np.float32)
+    py[:k] = (rng.integers(-3, rows + 3, k) + rng.choice([0.0, 0.5, 0.99999994, 1e-7], k)).astype(np.float32)
+    px[k:2 * k] = (rng.integers(-3, cols + 3, k) + rng.choice([0.0, 0.99999994, 0.9999999, 1e-8], k)).astype(np.float32)
+    # magnitudes where p +- 1 is no longer exact, and beyond i32
+    big = (np.exp2(rng.uniform(20, 40, k)) * rng.choice([-1.0, 1.0], k)).astype(np.float32)
+    px[2 * k:3 * k] = big
+    py[3 * k:3 * k + k // 2] = (np.exp2(rng.uniform(20, 40, k // 2)) * rng.choice([-1.0, 1.0], k // 2)).astype(np.float32)
+    special = np.array([np.nan, np.inf, -np.inf, -0.0, 0.0, -1.0, -0.99999994, 2147483648.0, -2147483904.0,
+                        cols - 1.0, cols - 2.0, cols - 1.0000001, 16777216.0, 16777215.0, 8388607.5], np.float32)
+    px[4 * k:4 * k + len(special)] = special
+    py[4 * k + len(special):4 * k + 2 * len(special)] = special
+    with np.errstate(all="ignore"):
+        want_g, want_c = oracle.sample_many(grid, px, py)
+        got_g, got_c = abi.selftest_field(grid, px, py)
+    bad = np.flatnonzero(~(bit_equal(got_g, want_g).all(axis=1) & bit_equal(got_c, want_c)))
+    assert len(bad) == 0, (f"{len(bad)} points differ, e.g. ({px[bad[0]]!r}, {py[bad[0]]!r}): "
+                           f"{got_g[bad[0]]} {got_c[bad[0]]} != {want_g[bad[0]]} {want_c[bad[0]]}")
+
+
 def test_pair_force_fuzz_hot_and_generic_forms_match_the_oracle(hip, oracle):
     """sfm.rs:130-153 pair by pair, 2 M random pairs including every edge of the hot form's
     validity range (device_math.hpp pair_force_hot): the device function both force kernels
