@@ -324,6 +324,90 @@ def _pair_fuzz_cases(rng, n):
     return pos, e, pos_i, vel
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_api_call_sequences_stay_in_lockstep(hip, oracle, seed):
+    """The C-ABI is a small state machine (appended / sorted / updated; keys and per-cell counts
+    fused into the previous update or not; gather or general sort form).  Random legal call
+    sequences -- spawns of any size incl. none, repeated passes, single updates, un-synced
+    batches, full-state appends, clears -- must keep the model bit-identical to the oracle
+    driven by the equivalent calls."""
+    sc = random_obstacle_scenario(70.0, 60, seed=seed)
+    field = oracle_field(oracle, sc)
+    rng = np.random.default_rng(100 + seed)
+    cpu = oracle.OracleModel(sc.field.size, seed=77)
+    gpu = _make_hip(hip, sc, field, seed=77, initial_capacity=1)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 4000, 4, seed=seed)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    is_sorted = True
+
+    def newcomers(k):
+        p, d, s, v = inject_crowd(field, sc.field.size, k, 4, seed=int(rng.integers(1 << 30)))
+        return p, d, s, v
+
+    def check(what):
+        assert gpu.get_pedestrian_count() == cpu.get_pedestrian_count(), what
+        _assert_state_equal(gpu.download(), cpu.download(), what)
+
+    log = []
+    for step in range(60):
+        op = rng.choice(["spawn", "spawn0", "update", "tick_n", "append", "clear", "acc", "check"],
+                        p=[0.2, 0.15, 0.2, 0.15, 0.1, 0.05, 0.05, 0.1])
+        log.append(op)
+        if op == "spawn":                      # spawn_pedestrians with arrivals (speeds drawn inside)
+            p, d, _, _ = newcomers(int(rng.integers(1, 300)))
+            cpu.spawn_pedestrians(field, p, d)
+            gpu.spawn_pedestrians(p, d)
+            is_sorted = True
+        elif op == "spawn0":                   # the bare sort/despawn pass, possibly twice in a row
+            cpu.spawn_pedestrians(field)
+            gpu.spawn_pedestrians()
+            is_sorted = True
+        elif op == "update":
+            if not is_sorted:
+                with pytest.raises(Exception, match="sort/despawn pass"):
+                    gpu.update_states()
+                continue
+            cpu.update_states(field)
+            gpu.update_states()
+            is_sorted = False
+        elif op == "tick_n":
+            k = int(rng.integers(1, 6))
+            gpu.tick_n(k)
+            for _ in range(k):
+                cpu.spawn_pedestrians(field)
+                cpu.update_states(field)
+            is_sorted = False
+        elif op == "append":                   # full-state injection, then a pass
+            p, d, s, v = newcomers(int(rng.integers(1, 500)))
+            gpu.append(p, d, s, v)
+            gpu.sort_despawn()
+            cpu.spawn_pedestrians(field, p, d, s, v)
+            is_sorted = True
+        elif op == "clear":
+            gpu.clear()
+            assert gpu.get_pedestrian_count() == 0
+            cpu = oracle.OracleModel(sc.field.size, seed=77)
+            gpu.set_speed_rng(77)              # a fresh oracle restarts its desired-speed stream
+            p, d, s, v = newcomers(1500)
+            gpu.append(p, d, s, v)
+            gpu.sort_despawn()
+            cpu.spawn_pedestrians(field, p, d, s, v)
+            is_sorted = True
+        elif op == "acc":
+            if is_sorted and cpu.get_pedestrian_count():
+                want = cpu.calc_accelerations(field)
+                got = gpu.calc_accelerations(len(want))
+                assert bit_equal(got, want).all(), f"step {step} {log[-8:]}"
+        else:
+            check(f"step {step} after {log[-8:]}")
+        if is_sorted:
+            assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices()), f"step {step} {log[-8:]}"
+    check(f"end, {log}")
+    gpu.close()
+
+
 def test_field_stencil_fuzz_patch_and_per_tap_forms(hip, oracle):
     """sobel_filter + bilinear (util.rs:44-75): the device evaluates the 3 x 3 taps from one
     4 x 4 texel patch and falls back to the literal per-tap form when rounding of p +- 1 moves
