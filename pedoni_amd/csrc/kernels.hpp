@@ -41,13 +41,13 @@ struct GridView {
     int32_t rows, cols; // NeighborGrid.shape = (rows, cols) (neighbor_grid.rs:14-20)
 };
 
-// neighbor_grid.rs:27-29: (pos / unit).as_ivec2() then Index::index_checked
-__device__ __forceinline__ int64_t cell_of(const GridView& g, v2 pos)
+// neighbor_grid.rs:27-29: (pos / unit).as_ivec2() then Index::index_checked; false = the
+// agent is outside the grid and is never binned
+__device__ __forceinline__ bool cell_xy(const GridView& g, v2 pos, int32_t& cx, int32_t& cy)
 {
-    int32_t ix = f32_as_i32(pos.x / g.unit);
-    int32_t iy = f32_as_i32(pos.y / g.unit);
-    if (ix < 0 || iy < 0 || iy >= g.rows || ix >= g.cols) return -1;
-    return (int64_t)iy * g.cols + ix;
+    cx = f32_as_i32(pos.x / g.unit);
+    cy = f32_as_i32(pos.y / g.unit);
+    return !(cx < 0 || cy < 0 || cy >= g.rows || cx >= g.cols);
 }
 
 // field.rs:235-239 get_potential(dest, pos) > 0.25 (sfm.rs:69,82); a destination with no
@@ -118,12 +118,11 @@ __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __res
     if (own || received) {
         float2 p = pos[i];
         v2 pp = mk(p.x, p.y);
-        int64_t c = cell_of(grid, pp);
-        if (c >= 0 && survives(field, pp, dest[i])) {
-            int32_t cy = (int32_t)(c / grid.cols), cx = (int32_t)(c - (int64_t)cy * grid.cols);
+        int32_t cx, cy;
+        if (cell_xy(grid, pp, cx, cy) && survives(field, pp, dest[i])) {
             // sharded runs keep only the band's rows plus one ghost row either side
             if (cy >= band_lo - 1 && cy <= band_hi) {
-                k = (uint32_t)c;
+                k = (uint32_t)cy * (uint32_t)grid.cols + (uint32_t)cx;
                 // agents appended since the last pass force the general form -- except the
                 // exchanged lists of a sharded run, which can only land in the four boundary
                 // rows, where count/write/reorder use the general form anyway
@@ -857,11 +856,10 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     // potential texels are the ones the goal stencil just touched, so they come from L1/L2)
     if (a.key_next) {
         uint32_t k = DEAD;
-        int64_t c = cell_of(a.grid, pos);
-        if (c >= 0 && survives(a.field, pos, a.dest[id])) {
-            int32_t cy = (int32_t)(c / a.grid.cols), cx = (int32_t)(c - (int64_t)cy * a.grid.cols);
+        int32_t cx, cy;
+        if (cell_xy(a.grid, pos, cx, cy) && survives(a.field, pos, a.dest[id])) {
             if (cy >= a.band_lo - 1 && cy <= a.band_hi) {
-                k = (uint32_t)c;
+                k = (uint32_t)cy * (uint32_t)a.grid.cols + (uint32_t)cx;
                 if (abs(cx - ix) > 1 || abs(cy - iy) > 1) atomicOr(&a.flags->far[a.parity_next], 1u);
             }
         }
@@ -1051,11 +1049,10 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
         vel[at] = make_float2(__uint_as_float(src[2]), __uint_as_float(src[3]));
         v0[at] = __uint_as_float(src[4]);
         dest[at] = d;
-        int64_t c = cell_of(grid, p);
-        if (c >= 0 && survives(field, p, d)) {
-            int32_t cy = (int32_t)(c / grid.cols);
+        int32_t cx, cy;
+        if (cell_xy(grid, p, cx, cy) && survives(field, p, d)) {
             if (cy >= band_lo - 1 && cy <= band_hi) {
-                kk = (uint32_t)c;
+                kk = (uint32_t)cy * (uint32_t)grid.cols + (uint32_t)cx;
                 // exchanged agents belong in the four boundary rows (general sort form there);
                 // anywhere else the whole pass must take the general form
                 if (!(cy <= band_lo || cy >= band_hi - 1)) atomicOr(&flags->far[parity], 1u);
