@@ -169,6 +169,8 @@ def main() -> None:
                     help="c3 = BASELINE metric workload (default, the only one the driver runs); "
                          "c2 = random-obstacle field with 1e5 agents; c4 = bottleneck x5 with 1e6 "
                          "agents (distance map); c4seg = same with explicit wall segments")
+    ap.add_argument("--density", type=float, default=DENSITY,
+                    help="c3 only: agents per m^2 (SURVEY 8(d) sweeps 0.25 / 1 / 4; the metric is quoted at 1)")
     ap.add_argument("--work-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -218,11 +220,12 @@ def main() -> None:
 
     G = args.gpus
     n_per = args.agents_per_gpu
-    side = float(np.sqrt(n_per / DENSITY))          # 1000 m at 1e6 agents
+    density = args.density
+    side = float(np.sqrt(n_per / density))          # 1000 m at 1e6 agents and rho = 1
     width, height = side, side * G
     obstacles, waypoints = box_geometry(width, height)
     workload = (f"uniform crowd N={n_per * G:.0e} ({n_per:.0e}/GPU) in a {width:.0f}x{height:.0f} m box, "
-                f"rho={DENSITY:g}/m^2, neighbor grid 1.4 m, field maps 0.25 m, fp32").replace("e+0", "e")
+                f"rho={density:g}/m^2, neighbor grid 1.4 m, field maps 0.25 m, fp32").replace("e+0", "e")
 
     custom_crowd = None
     if args.workload != "c3":
@@ -245,7 +248,7 @@ def main() -> None:
         from pedoni_amd.sharded import ShardedModel
         model.set_stream(stream.cuda_stream)
         runner = ShardedModel(model, rank, G, dist, torch,
-                              expected_row_agents=int(width * 1.4 * DENSITY),
+                              expected_row_agents=int(width * 1.4 * density),
                               overlap=os.environ.get("PEDONI_OVERLAP") == "1")
         # this rank's agents: exactly its own band of grid rows (2 m clear of the outer walls)
         y_lo, y_hi = runner.lo * 1.4 + 0.01, runner.hi * 1.4 - 0.01
