@@ -810,3 +810,33 @@ def test_queue_and_simple_force_kernels_agree(hip, oracle, monkeypatch):
         got = gpu.calc_accelerations(len(want))
         assert bit_equal(got, want).all(), f"PEDONI_FORCE_SIMPLE={simple}"
         gpu.close()
+
+
+def test_create_destroy_does_not_leak_device_memory(hip, oracle):
+    """pedoni_hip_destroy must return everything pedoni_hip_create, capacity growth, sharding,
+    profiling and the spawners allocated."""
+    import torch
+    sc = random_obstacle_scenario(80.0, 40)
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 20_000, 4, seed=3)
+
+    def cycle(k):
+        gpu = _make_hip(hip, sc, field, initial_capacity=1)
+        if k % 2:
+            gpu.set_band(10, 40, 2048)
+        gpu.append(pos, dest, v0, vel)        # grows the arrays several times
+        gpu.sort_despawn()
+        if not k % 2:
+            gpu.profile(True)
+            gpu.tick_n(3)
+            gpu.kernel_times(reset=True)
+        gpu.close()
+
+    cycle(0); cycle(1)                        # warm the allocator's own pools
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(12):
+        cycle(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of device memory not returned"
