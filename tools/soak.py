@@ -1,6 +1,6 @@
 """One-off long soak (not part of the suite): N agents, T ticks free-running on the GPU, then a
 bitwise comparison with the oracle's own T ticks.
-    python tools/soak.py [N=200000] [T=3000]"""
+    python tools/soak.py [N=200000] [T=3000] [segments]     (segments: use_distance_map = false)"""
 import sys
 import time
 from pathlib import Path
@@ -15,11 +15,12 @@ from oracle import pyoracle as oracle         # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
-sc = random_obstacle_scenario(360.0, 700, seed=8)
+segments = len(sys.argv) > 3 and sys.argv[3] == "segments"
+sc = random_obstacle_scenario(360.0, 30 if segments else 700, seed=8)
 field = oracle_field(oracle, sc)
 pos, dest, v0, vel = inject_crowd(field, sc.field.size, n, 4, seed=13)
-cpu = oracle.OracleModel(sc.field.size)
-gpu = hip.HipModel(hip.Options(), sc.field.size, field.distance_map, field.potential_maps, field.unit,
+cpu = oracle.OracleModel(sc.field.size, use_distance_map=not segments)
+gpu = hip.HipModel(hip.Options(use_distance_map=not segments), sc.field.size, field.distance_map, field.potential_maps, field.unit,
                    sc.obstacle_array())
 cpu.spawn_pedestrians(field, pos, dest, v0, vel)
 gpu.append(pos, dest, v0, vel)
@@ -31,7 +32,7 @@ for chunk in (T // 3, T // 3, T - 2 * (T // 3)):
     t1 = time.time()
     for _ in range(chunk):
         cpu.spawn_pedestrians(field)
-        cpu.update_states(field)
+        cpu.update_states(field, sc.obstacle_array() if segments else None)
     wp, wd, wv, w0 = cpu.download()
     done += chunk
     same = len(gp) == len(wp) and np.array_equal(gd, wd) and bit_equal(gp, wp).all() and \
