@@ -82,20 +82,14 @@ def free_space_crowd(field, size, n, n_dest, seed, dest_rule=None):
 
 def other_workload(name):
     """BASELINE.json configs[1] (C2) and configs[3] (C4) as optional bench workloads."""
-    if name == "c2":       # random.toml-style: 200 x 200 m, 4 corner waypoints, 1004 thin walls
-        L, rng = 200.0, np.random.default_rng(7)
-        a, b = 0.05 * L, 0.1 * L
-        waypoints = np.array([[a, b, b, a, 1], [L - a, b, L - b, a, 1], [a, L - b, b, L - a, 1],
-                              [L - a, L - b, L - b, L - a, 1]], np.float32)
-        walls = [[0, 0, 0, L, 0.2], [0, L, L, L, 0.2], [0, 0, L, 0, 0.2], [L, 0, L, L, 0.2]]
-        for _ in range(1000):
-            c, ang = rng.uniform(0.05 * L, 0.95 * L, 2), rng.uniform(0, np.pi)
-            d = np.array([np.cos(ang), np.sin(ang)]) * 2.5
-            walls.append([*(c - d), *(c + d), 0.2])
-        obstacles = np.array(walls, np.float32)
+    if name == "c2":       # scenarios/random.toml (data fixture): 200 x 200 m, 4 waypoints, 1004 walls
+        from pedoni_amd import scenario as scn
+        sc = scn.load(ROOT / "tests" / "golden" / "scenarios" / "random.toml")
+        L = float(sc.field.size[0])
+        obstacles, waypoints = sc.obstacle_array(), sc.waypoint_array()
         crowd = lambda field: free_space_crowd(field, (L, L), 100_000, 4, seed=100)
         return obstacles, waypoints, (L, L), crowd, \
-            "random-obstacle field 200x200 m, 1004 walls, N=1e5 injected agents (rho~2.5/m^2), 4 destinations"
+            "scenarios/random.toml geometry (200x200 m, 1004 obstacles), N=1e5 injected agents (rho~2.5/m^2), 4 destinations"
     # bottleneck.toml geometry x5 (tests/golden/scenarios/bottleneck_x5.toml)
     obstacles = np.array([[250, 0, 500, 450, 25], [250, 1000, 500, 550, 25], [750, 0, 500, 450, 25],
                           [750, 1000, 500, 550, 25]], np.float32)

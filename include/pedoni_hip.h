@@ -124,7 +124,9 @@ int pedoni_hip_append(PedoniModel* m, const float* pos_xy, const uint32_t* desti
                       const float* desired_speed, const float* vel_xy, uint32_t n);
 /* [ext] the sort/despawn half of spawn_pedestrians alone (sfm.rs:58-88) */
 int pedoni_hip_sort_despawn(PedoniModel* m);
-/* [ext] `steps` x (sort_despawn; update_states) with no host round trip in between */
+/* [ext] `steps` x (sort_despawn; update_states) with no host round trip in between; in steady
+ * state (nothing appended, no exchange, no device spawning) pairs of ticks are replayed from a
+ * captured hipGraph -- same kernels, one launch per pair (PEDONI_NO_GRAPH=1 disables it) */
 int pedoni_hip_tick_n(PedoniModel* m, uint32_t steps);
 /* [ext] one Simulator::tick-shaped step with StepMetrics (lib.rs:64-100), no new agents */
 int pedoni_hip_tick(PedoniModel* m, PedoniStepMetrics* metrics);
@@ -211,6 +213,12 @@ int pedoni_hip_halo_tick_begin(PedoniModel* m, const void* from_below_dev,
 int pedoni_hip_halo_tick_end(PedoniModel* m);
 /* owned-agent count (excludes ghosts) */
 int pedoni_hip_owned_count(PedoniModel* m, int32_t* count);
+
+/* [ext] test hook: overwrite the model's sticky device status word (the word the scan and
+ * place kernels raise when cell and row counts disagree or the live count exceeds the host's
+ * bound of the arrays).  While it is non-zero every read of device state -- get_pedestrian_count,
+ * download, list_pedestrians, owned_count -- fails with PEDONI_E_HIP / PEDONI_E_CAPACITY. */
+int pedoni_hip_debug_set_status(PedoniModel* m, uint32_t status_word);
 
 /* [ext] device self-test hooks used by tests/: evaluate one device math primitive over
  * host arrays (op: 0 = a/b, 1 = sqrt(a), 2 = exp(a), 3 = a/0.3f, 4 = a/0.2f,

@@ -46,40 +46,85 @@ void oracle_field_shape(float size_x, float size_y, float unit, int32_t* rows, i
 
 /* ---- rasterisation ------------------------------------------------------------
  * field.rs:42-64,66-88 rasterise a CLOSED LineString (the 4-vertex rectangle of
- * util::line_with_width, scaled by 1/unit) with geo-rasterize 0.1.2
- * (Cargo.lock:488-489; source not under /root/reference).  That crate documents its
- * line algorithm as a port of GDAL's all-touched line burner: every pixel the segment
- * passes through is set.  parity unpinned: restated from the published description;
- * the reference's tests only print the result (field.rs:272-286).  It affects how the
- * INPUT maps are produced, not the per-step arithmetic.
+ * util::line_with_width, scaled by 1/unit; f32 coordinates, converted to f64 by the crate)
+ * with geo-rasterize 0.1.2 (Cargo.lock:488-489; source not under /root/reference).
  *
- * Implementation: exact supercover walk of each edge over the unit pixel grid
- * (pixel (c, r) covers [c, c+1) x [r, r+1)), in double.
+ * PARITY UNPINNED.  The crate documents its rasterisation as ports of GDAL's burners --
+ * filled polygons from GDALdllImageFilledPolygon, line strings from
+ * GDALdllImageLineAllTouched -- checked against GDAL by property tests.  What follows
+ * restates THAT published algorithm (GDAL alg/llrasterize.cpp, all-touched line burner):
+ * left-to-right segments; a segment that stays in one pixel column, or is closer than 0.01
+ * to vertical, burns a straight run of that column (likewise rows for near-horizontal ones);
+ * anything else is walked pixel by pixel along x with the slope, moving to the next
+ * scanline whenever the step to the next column would cross a row boundary, nudged by 1e-9
+ * so that it always advances.  Written independently of the product's builder
+ * (pedoni_amd/csrc/host/field.cpp, an exact grid traversal): the two agreeing is evidence
+ * for "every touched pixel", not a pin -- the reference's own test of the crate only prints
+ * (field.rs:272-286).  Affects how the INPUT maps are produced, not the per-step arithmetic.
  */
 static void burn(uint8_t* mask, int32_t rows, int32_t cols, int64_t c, int64_t r)
 {
     if (c >= 0 && r >= 0 && c < cols && r < rows) mask[(size_t)r * cols + c] = 1;
 }
 
-static void burn_segment(uint8_t* mask, int32_t rows, int32_t cols,
-                         double x0, double y0, double x1, double y1)
-{
-    double dx = x1 - x0, dy = y1 - y0;
-    int64_t c = (int64_t)floor(x0), r = (int64_t)floor(y0);
-    int64_t c_end = (int64_t)floor(x1), r_end = (int64_t)floor(y1);
-    int64_t sc = dx > 0 ? 1 : -1, sr = dy > 0 ? 1 : -1;
-    /* parametric distance to the next vertical / horizontal pixel boundary */
-    double t_max_x = dx != 0 ? ((dx > 0 ? (double)(c + 1) : (double)c) - x0) / dx : INFINITY;
-    double t_max_y = dy != 0 ? ((dy > 0 ? (double)(r + 1) : (double)r) - y0) / dy : INFINITY;
-    double t_dx = dx != 0 ? fabs(1.0 / dx) : INFINITY;
-    double t_dy = dy != 0 ? fabs(1.0 / dy) : INFINITY;
-    int64_t guard = llabs(c_end - c) + llabs(r_end - r) + 4;
+static void swap_d(double* a, double* b) { double t = *a; *a = *b; *b = t; }
 
-    burn(mask, rows, cols, c, r);
-    while ((c != c_end || r != r_end) && guard-- > 0) {
-        if (t_max_x < t_max_y) { t_max_x += t_dx; c += sc; }
-        else                   { t_max_y += t_dy; r += sr; }
-        burn(mask, rows, cols, c, r);
+static void burn_segment(uint8_t* mask, int32_t rows, int32_t cols,
+                         double x, double y, double x_end, double y_end)
+{
+    const double w = (double)cols, h = (double)rows;
+    /* segments wholly off the raster */
+    if ((y < 0 && y_end < 0) || (y > h && y_end > h) || (x < 0 && x_end < 0) || (x > w && x_end > w)) return;
+    if (x > x_end) { swap_d(&x, &x_end); swap_d(&y, &y_end); }       /* proceed left to right */
+
+    if (floor(x) == floor(x_end) || fabs(x - x_end) < 0.01) {         /* (near) vertical */
+        if (y_end < y) swap_d(&y, &y_end);
+        const int64_t ix = (int64_t)floor(x_end);
+        int64_t iy = (int64_t)floor(y), iy_end = (int64_t)floor(y_end);
+        if (ix < 0 || ix >= cols) return;
+        if (iy < 0) iy = 0;
+        if (iy_end >= rows) iy_end = rows - 1;
+        for (; iy <= iy_end; ++iy) burn(mask, rows, cols, ix, iy);
+        return;
+    }
+    if (floor(y) == floor(y_end) || fabs(y - y_end) < 0.01) {         /* (near) horizontal */
+        int64_t ix = (int64_t)floor(x), ix_end = (int64_t)floor(x_end);
+        const int64_t iy = (int64_t)floor(y);
+        if (iy < 0 || iy >= rows) return;
+        if (ix < 0) ix = 0;
+        if (ix_end >= cols) ix_end = cols - 1;
+        for (; ix <= ix_end; ++ix) burn(mask, rows, cols, ix, iy);
+        return;
+    }
+
+    const double slope = (y_end - y) / (x_end - x);
+    if (x_end > w) { y_end -= (x_end - w) * slope; x_end = w; }       /* clip in x */
+    if (x < 0.0) { y += (0.0 - x) * slope; x = 0.0; }
+    if (y_end > y) {                                                   /* clip in y */
+        if (y < 0.0) { x += (0.0 - y) / slope; y = 0.0; }
+        if (y_end >= h) x_end += (y_end - h) / slope;
+    } else {
+        if (y >= h) { x += (h - y) / slope; y = h; }
+        if (y_end < 0.0) x_end -= (y_end - 0.0) / slope;
+    }
+    while (x >= 0.0 && x < x_end) {                                    /* pixel to pixel */
+        const int64_t ix = (int64_t)floor(x), iy = (int64_t)floor(y);
+        if (iy >= 0 && iy < rows) burn(mask, rows, cols, ix, iy);
+        double step_x = floor(x + 1.0) - x;
+        double step_y = step_x * slope;
+        if ((int64_t)floor(y + step_y) == iy) {                        /* next column, same scanline */
+            x += step_x; y += step_y;
+        } else if (slope < 0) {
+            step_y = (double)iy - y;
+            if (step_y > -0.000000001) step_y = -0.000000001;
+            step_x = step_y / slope;
+            x += step_x; y += step_y;
+        } else {
+            step_y = (double)(iy + 1) - y;
+            if (step_y < 0.000000001) step_y = 0.000000001;
+            step_x = step_y / slope;
+            x += step_x; y += step_y;
+        }
     }
 }
 

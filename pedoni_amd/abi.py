@@ -39,6 +39,7 @@ SYMBOLS = [
     "pedoni_hip_halo_tick_begin", "pedoni_hip_halo_tick_end",
     "pedoni_hip_owned_count",
     "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_selftest_field", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
+    "pedoni_hip_debug_set_status",
 ]
 
 
@@ -396,3 +397,7 @@ class HipModel:
         c = C.c_int32(0)
         _check(self._lib, self._lib.pedoni_hip_owned_count(self._h, C.byref(c)))
         return int(c.value)
+
+    def debug_set_status(self, word: int) -> None:
+        """Test hook: overwrite the sticky device status word (0 clears it)."""
+        _check(self._lib, self._lib.pedoni_hip_debug_set_status(self._h, C.c_uint32(word)))

@@ -54,7 +54,17 @@ inline float float_of(uint32_t u)
     return v;
 }
 
-// every pixel a segment passes through (geo-rasterize's line burner)
+// Line burner of a closed LineString (field.rs:42-64,66-88 -> geo-rasterize 0.1.2).
+// PARITY UNPINNED: the crate's source is not under /root/reference and upstream's only test
+// of it prints (field.rs:272-286).  The crate documents its line rasterisation as a port of
+// GDAL's all-touched burner (alg/llrasterize.cpp, GDALdllImageLineAllTouched), so that
+// published algorithm is what is followed here: runs of one pixel column / row for segments
+// within one column / row or closer than 0.01 to vertical / horizontal, otherwise a
+// left-to-right walk in which each step either enters the next pixel column on the same
+// scanline or moves to the scanline boundary (1e-9 nudge).  Differs from an exact grid
+// traversal only where a segment passes through a pixel corner or ends on a pixel edge
+// (19 of ~250 000 burnt cells over the reference's 14 scenario files;
+// tests/test_host_cpu.py::test_line_burner_is_all_touched_up_to_corner_ties).
 struct Burner {
     uint8_t* mask;
     int64_t rows, cols;
@@ -62,22 +72,51 @@ struct Burner {
     {
         if (c >= 0 && r >= 0 && c < cols && r < rows) mask[(size_t)r * cols + c] = 1;
     }
-    void segment(double x0, double y0, double x1, double y1) const
+    void column_run(int64_t c, double ya, double yb) const
     {
-        const double dx = x1 - x0, dy = y1 - y0;
-        int64_t c = (int64_t)std::floor(x0), r = (int64_t)std::floor(y0);
-        const int64_t c_end = (int64_t)std::floor(x1), r_end = (int64_t)std::floor(y1);
-        const int64_t sc = dx > 0 ? 1 : -1, sr = dy > 0 ? 1 : -1;
-        double tx = dx != 0 ? ((dx > 0 ? (double)(c + 1) : (double)c) - x0) / dx : INFINITY;
-        double ty = dy != 0 ? ((dy > 0 ? (double)(r + 1) : (double)r) - y0) / dy : INFINITY;
-        const double ddx = dx != 0 ? std::fabs(1.0 / dx) : INFINITY;
-        const double ddy = dy != 0 ? std::fabs(1.0 / dy) : INFINITY;
-        int64_t budget = std::llabs(c_end - c) + std::llabs(r_end - r) + 4;
-        set(c, r);
-        while ((c != c_end || r != r_end) && budget-- > 0) {
-            if (tx < ty) { tx += ddx; c += sc; }
-            else         { ty += ddy; r += sr; }
-            set(c, r);
+        if (c < 0 || c >= cols) return;
+        const int64_t r0 = std::max<int64_t>((int64_t)std::floor(std::min(ya, yb)), 0);
+        const int64_t r1 = std::min<int64_t>((int64_t)std::floor(std::max(ya, yb)), rows - 1);
+        for (int64_t r = r0; r <= r1; ++r) set(c, r);
+    }
+    void row_run(int64_t r, double xa, double xb) const
+    {
+        if (r < 0 || r >= rows) return;
+        const int64_t c0 = std::max<int64_t>((int64_t)std::floor(xa), 0);
+        const int64_t c1 = std::min<int64_t>((int64_t)std::floor(xb), cols - 1);
+        for (int64_t c = c0; c <= c1; ++c) set(c, r);
+    }
+    void segment(double ax, double ay, double bx, double by) const
+    {
+        const double W = (double)cols, H = (double)rows;
+        if ((ay < 0 && by < 0) || (ay > H && by > H) || (ax < 0 && bx < 0) || (ax > W && bx > W)) return;
+        if (ax > bx) { std::swap(ax, bx); std::swap(ay, by); }            // a is the left end
+        if (std::floor(ax) == std::floor(bx) || std::fabs(ax - bx) < 0.01)
+            return column_run((int64_t)std::floor(bx), ay, by);
+        if (std::floor(ay) == std::floor(by) || std::fabs(ay - by) < 0.01)
+            return row_run((int64_t)std::floor(ay), ax, bx);
+        const double m = (by - ay) / (bx - ax);
+        // clip to the raster: x first, then the end that leaves in y
+        if (bx > W) { by -= (bx - W) * m; bx = W; }
+        if (ax < 0.0) { ay += (0.0 - ax) * m; ax = 0.0; }
+        if (by > ay) {
+            if (ay < 0.0) { ax += (0.0 - ay) / m; ay = 0.0; }
+            if (by >= H) bx += (by - H) / m;
+        } else {
+            if (ay >= H) { ax += (H - ay) / m; ay = H; }
+            if (by < 0.0) bx -= (by - 0.0) / m;
+        }
+        double x = ax, y = ay;
+        while (x >= 0.0 && x < bx) {
+            const int64_t c = (int64_t)std::floor(x), r = (int64_t)std::floor(y);
+            if (r >= 0 && r < rows) set(c, r);
+            double sx = std::floor(x + 1.0) - x, sy = sx * m;            // to the next pixel column
+            if ((int64_t)std::floor(y + sy) != r) {                        // a scanline boundary comes first
+                sy = m < 0 ? std::min((double)r - y, -0.000000001) : std::max((double)(r + 1) - y, 0.000000001);
+                sx = sy / m;
+            }
+            x += sx;
+            y += sy;
         }
     }
     // closed LineString through the 4 vertices (field.rs:44-53 `shape.close()`)

@@ -91,7 +91,16 @@ void SocialForceModelHip::spawn_pedestrians(const Field&, std::vector<Pedestrian
 
 void SocialForceModelHip::update_states(const Scenario&, const Field&)
 {
+    // device time of the force + integrate kernel, from the library's hipEvent pair
+    // (diagnostic.rs:45-50 time_calc_state_kernel; upstream's OpenCL model reads its event's
+    // start / end and then drops them, sfm_gpu.rs:234-236, lib.rs:98)
+    check(pedoni_hip_profile(model_, 1 << PEDONI_K_FORCE), "update_states");
     check(pedoni_hip_update_states(model_), "update_states");
+    PedoniKernelTimes t{};
+    check(pedoni_hip_kernel_times(model_, &t, /*reset=*/1), "update_states");
+    check(pedoni_hip_profile(model_, 0), "update_states");
+    last_kernel_s_ = t.launches[PEDONI_K_FORCE] ? std::optional<double>(t.total_ms[PEDONI_K_FORCE] * 1e-3)
+                                                : std::nullopt;   // no agents: nothing was launched
 }
 
 std::vector<Pedestrian> SocialForceModelHip::list_pedestrians() const
@@ -355,7 +364,8 @@ StepMetrics Simulator::tick()
     m.active_ped_count = model->get_pedestrian_count();
     m.time_spawn = time_spawn;
     m.time_calc_state = time_calc_state;
-    m.time_calc_state_kernel = std::nullopt; // upstream: always None (lib.rs:98)
+    // upstream leaves this None (lib.rs:98); SURVEY 8(f) rank 4 asks the backend to fill it
+    m.time_calc_state_kernel = hip ? hip->last_kernel_seconds() : std::nullopt;
     return m;
 }
 

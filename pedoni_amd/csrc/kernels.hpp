@@ -11,8 +11,10 @@
 //   cell_count[cells+1], cell_start[2][cells+1] u32 (= the reference's neighbor_grid_indices;
 //   ping-pong: the gather sort form reads last tick's while writing this tick's)
 //   field maps: distance_map + n potential maps, row-major (y, x) f32
+//   row_count[rows+1] u32: members per grid row (the scan's top level)
 // Kernels per tick in steady state: scan -> place (-> reorder: no-op) -> force; the per-cell
-// counts the scan consumes are accumulated by the force kernel's tail (integer atomics).
+// and per-row counts the scan consumes are accumulated by the force kernel's tail (integer
+// atomics).
 #pragma once
 
 #include "device_math.hpp"
@@ -82,6 +84,34 @@ struct SortFlags {
 
 __device__ __forceinline__ uint32_t pack_cell(uint32_t cx, uint32_t cy) { return (cy << 16) | cx; }
 
+// Sticky device status word (PedoniModel::d_live[1]); every host read of the live count
+// returns PEDONI_E_HIP / PEDONI_E_CAPACITY while a bit is set -- nothing continues silently.
+constexpr uint32_t STATUS_SCAN_MISMATCH = 1u; // a row's cell counts do not add up to its row count
+constexpr uint32_t STATUS_LIVE_OVERFLOW = 2u; // more live agents than the host's bound of the arrays
+
+// Every stored key is followed by one count on its cell AND one on its grid row: the scan
+// (scan_rows_kernel) turns the row totals into each row's first index without any
+// inter-workgroup hand-off.  Integer atomics: exact in any arrival order.  The row add is
+// aggregated over the wave first (sorted agents: a wave spans one or two rows), so it costs
+// one or two atomics per wave.  Call with the lanes that have a key to count; `todo` false
+// lanes only take part in the ballots.
+__device__ __forceinline__ void count_key(uint32_t* __restrict__ cell_count, uint32_t* __restrict__ row_count,
+                                          bool todo, uint32_t k, uint32_t cy)
+{
+    if (todo) atomicAdd(&cell_count[k], 1u);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (;;) {
+        const unsigned long long pending = __ballot(todo);
+        if (pending == 0ull) break;
+        const int leader = __ffsll((long long)pending) - 1;
+        const uint32_t row = (uint32_t)__shfl((int)cy, leader, 64);
+        const bool same = todo && cy == row;
+        const unsigned long long group = __ballot(same);
+        if ((int)lane == leader) atomicAdd(&row_count[row], (uint32_t)__popcll(group));
+        todo = todo && !same;
+    }
+}
+
 // ---- K_KEY (PEDONI_K_BIN) ----------------------------------------------------------------
 // One thread per stored agent.  Slots [live, gap_end) hold agents despawned by earlier
 // ticks (the host only knows an upper bound of the live count) and are skipped.
@@ -103,7 +133,8 @@ __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __res
                            const HaloIn* __restrict__ halo, FieldView field, GridView grid,
                            int32_t band_lo, int32_t band_hi, const uint32_t* __restrict__ skey_old,
                            int32_t force_general, uint32_t parity, SortFlags* __restrict__ flags,
-                           uint32_t* __restrict__ key, uint32_t* __restrict__ cell_count)
+                           uint32_t* __restrict__ key, uint32_t* __restrict__ cell_count,
+                           uint32_t* __restrict__ row_count)
 {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0 && force_general) atomicOr(&flags->far[parity], 1u);
@@ -115,10 +146,10 @@ __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __res
     bool own = i >= base && i < live;
     bool received = (i < base && i >= base - n_below) || (i >= gap_end && i < app_end);
     uint32_t k = DEAD;
+    int32_t cx = 0, cy = 0;
     if (own || received) {
         float2 p = pos[i];
         v2 pp = mk(p.x, p.y);
-        int32_t cx, cy;
         if (cell_xy(grid, pp, cx, cy) && survives(field, pp, dest[i])) {
             // sharded runs keep only the band's rows plus one ghost row either side
             if (cy >= band_lo - 1 && cy <= band_hi) {
@@ -138,7 +169,7 @@ __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __res
         }
     }
     key[i] = k;
-    if (k != DEAD) atomicAdd(&cell_count[k], 1u);   // integer, so exact in any arrival order
+    count_key(cell_count, row_count, k != DEAD, k, (uint32_t)cy);
 }
 
 // the three old index ranges that can hold members of new cell (cx, cy)
@@ -283,80 +314,57 @@ scan_apply_kernel(uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restr
     }
 }
 
-// ---- single-pass scan (decoupled look-back) ---------------------------------------------------
-// One launch instead of three: every block scans its 2048-element tile, publishes its
-// aggregate, and resolves its exclusive prefix by walking back over its predecessors'
-// published words.  A word packs {epoch, state, value} so nothing needs zeroing between
-// launches (the epoch changes) and a single relaxed agent-scope 64-bit access carries both
-// flag and data (MI355X_MICROARCH: sc1 accesses bypass the non-coherent L1).  Tiles are
-// handed out by an atomic ticket, so a block only ever waits for blocks that already run.
-struct ScanState {
-    unsigned long long* words; // one per tile
-    uint32_t* ticket;          // reset by the block that draws the last ticket
-};
-
-__device__ __forceinline__ unsigned long long scan_word(uint32_t epoch, uint32_t state, uint32_t v)
-{
-    return ((unsigned long long)epoch << 34) | ((unsigned long long)state << 32) | v;
-}
-
+// ---- row scan: neighbor_grid_indices in one launch, no inter-workgroup hand-off -----------
+// One workgroup per grid row.  Whoever stored a key also counted it on its row (count_key),
+// so a row's first index is base + the sum of the row totals before it -- a few hundred
+// words every workgroup adds up for itself -- and the cells of the row are then scanned
+// locally.  Nothing waits on another workgroup (the decoupled look-back scan this replaces
+// spun on its predecessors' status words).  Zeroes the cell counts it consumes; the row
+// counts are zeroed by the place kernel that follows (every workgroup here reads them).
+// Integrity: a row whose cell counts do not add up to its row count, or a live total above
+// the host's bound of the arrays, sets a sticky status bit.
 __global__ void __launch_bounds__(SCAN_THREADS)
-scan_single_kernel(uint32_t* __restrict__ in, uint32_t n, uint32_t base, uint32_t* __restrict__ out,
-                   uint32_t* __restrict__ total_out2, int zero_input, ScanState st, uint32_t epoch)
+scan_rows_kernel(uint32_t* __restrict__ cell_count, const uint32_t* __restrict__ row_count, int32_t row0,
+                 int32_t cols, uint32_t base, uint32_t* __restrict__ out, uint32_t* __restrict__ live_out,
+                 uint32_t limit, uint32_t* __restrict__ status)
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64];
-    __shared__ uint32_t tile_s, prefix_s;
-    if (threadIdx.x == 0) {
-        uint32_t t = atomicAdd(st.ticket, 1u);
-        if (t == gridDim.x - 1) *st.ticket = 0;            // every ticket has been drawn
-        tile_s = t;
-    }
-    __syncthreads();
-    const uint32_t tile = tile_s;
-    uint32_t first = tile * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
-    uint32_t v[SCAN_PER_THREAD];
-    uint32_t s = 0;
+    const int32_t row = row0 + (int32_t)blockIdx.x;
+    uint32_t part = 0;
+    for (int32_t r = row0 + (int32_t)threadIdx.x; r < row; r += SCAN_THREADS) part += row_count[r];
+    uint32_t before;
+    block_exclusive_scan(part, lds, before);
+    uint32_t carry = base + before;
+    uint32_t* in = cell_count + (size_t)row * (size_t)cols;
+    uint32_t* o = out + (size_t)row * (size_t)cols;
+    for (int32_t c0 = 0; c0 < cols; c0 += SCAN_THREADS * 4) {
+        const int32_t first = c0 + (int32_t)threadIdx.x * 4;
+        uint32_t v[4];
+        uint32_t s = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        v[k] = first + k < n ? in[first + k] : 0;
-        s += v[k];
-    }
-    uint32_t aggregate;
-    uint32_t ex = block_exclusive_scan(s, lds, aggregate);
-    // publish the tile's aggregate first, then add up ALL predecessors' aggregates with the
-    // whole block: no tile waits on another tile's prefix, only on its (early) aggregate
-    if (threadIdx.x == 0)
-        __hip_atomic_store(&st.words[tile], scan_word(epoch, 1, aggregate), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t partial = 0;
-    for (uint32_t p = threadIdx.x; p < tile; p += SCAN_THREADS) {
-        unsigned long long w;
-        uint32_t spins = 0;                                  // bounded: the predecessor holds an
-        do {                                                 // earlier ticket, so it already runs
-            w = __hip_atomic_load(&st.words[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (++spins > (1u << 22)) break;
-            if (spins > 8) __builtin_amdgcn_s_sleep(1);
-        } while ((uint32_t)(w >> 34) != epoch);
-        partial += (uint32_t)w;
-    }
-    uint32_t before_total;
-    block_exclusive_scan(partial, lds, before_total);
-    if (threadIdx.x == 0) {
-        prefix_s = base + before_total;
-        if (tile == gridDim.x - 1) {
-            out[n] = base + before_total + aggregate;
-            if (total_out2) *total_out2 = base + before_total + aggregate;
+        for (int k = 0; k < 4; ++k) {
+            v[k] = first + k < cols ? in[first + k] : 0u;
+            s += v[k];
         }
-    }
-    __syncthreads();
-    ex += prefix_s;
+        uint32_t total;
+        uint32_t ex = carry + block_exclusive_scan(s, lds, total);
 #pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        if (first + k < n) {
-            out[first + k] = ex;
-            if (zero_input) in[first + k] = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (first + k < cols) {
+                o[first + k] = ex;
+                in[first + k] = 0;
+            }
+            ex += v[k];
         }
-        ex += v[k];
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        if (carry - (base + before) != row_count[row]) atomicOr(status, STATUS_SCAN_MISMATCH);
+        if (blockIdx.x == gridDim.x - 1) {
+            o[cols] = carry;             // out[(row + 1) * cols]: the end of the last scanned row
+            *live_out = carry;
+            if (carry > limit) atomicOr(status, STATUS_LIVE_OVERFLOW);
+        }
     }
 }
 
@@ -388,16 +396,22 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
                              GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
                              const uint32_t* __restrict__ cs_new, SortFlags* __restrict__ flags,
                              uint32_t parity, uint32_t* __restrict__ cell_count, SoA a,
-                             uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed)
+                             uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed,
+                             uint32_t* __restrict__ row_count, int32_t row0, int32_t row1,
+                             uint32_t* __restrict__ status)
 {
     uint32_t j = i0 + xcd_contiguous_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     // the NEXT tick's flag is raised by this tick's update_states and the next K_KEY; it can
     // be cleared here because every key of this tick has been written and nothing reads it now
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        flags->far[parity ^ 1u] = 0;
-        // the agents stored by the device since the last pass (exchanged lists, device spawns)
-        // have their keys: mark them consumed
-        if (halo_consumed) halo_consumed->n_below = halo_consumed->n_above = halo_consumed->counted = 0;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            flags->far[parity ^ 1u] = 0;
+            // the agents stored by the device since the last pass (exchanged lists, device
+            // spawns) have their keys: mark them consumed
+            if (halo_consumed) halo_consumed->n_below = halo_consumed->n_above = halo_consumed->counted = 0;
+        }
+        // the scan has consumed the row totals: back to zero for the keys of the next pass
+        for (int32_t r = row0 + (int32_t)threadIdx.x; r < row1; r += (int32_t)blockDim.x) row_count[r] = 0;
     }
     if (j >= n_total) return;
     uint32_t c = key[j];
@@ -411,9 +425,15 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
             const uint32_t hi = min(r.hi[k], j);
             for (uint32_t i = r.lo[k]; i < hi; ++i) before += key[i] == c ? 1u : 0u;
         }
-        move_agent(a, j, cs_new[c] + before, pack_cell(cx, cy));
+        const uint32_t to = cs_new[c] + before;
+        // (never taken unless the live count exceeds the host's bound: scan_rows_kernel has
+        // raised STATUS_LIVE_OVERFLOW then; do not write past the arrays)
+        if (to < n_total) move_agent(a, j, to, pack_cell(cx, cy));
+        else atomicOr(status, STATUS_LIVE_OVERFLOW);
     } else {
-        slots[cs_new[c] + atomicAdd(&cell_count[c], 1u)] = j;
+        const uint32_t to = cs_new[c] + atomicAdd(&cell_count[c], 1u);
+        if (to < n_total) slots[to] = j;
+        else atomicOr(status, STATUS_LIVE_OVERFLOW);
     }
 }
 
@@ -449,10 +469,10 @@ __global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, ui
         if (k == DEAD) continue;
         uint32_t cy = k / (uint32_t)grid.cols, cx = k - cy * (uint32_t)grid.cols;
         if (!general_cell(flags, parity, band, (int32_t)cy)) continue;
-        uint32_t base = cs_new[k], end = cs_new[k + 1];
+        uint32_t base = cs_new[k], end = min(cs_new[k + 1], n_total);
         uint32_t before = 0;
         for (uint32_t j = base; j < end; ++j) before += slots[j] < i ? 1u : 0u;
-        move_agent(a, i, base + before, pack_cell(cx, cy));
+        if (base + before < n_total) move_agent(a, i, base + before, pack_cell(cx, cy));
         cell_count[k] = 0;   // the provisional-slot counter, back to zero for the next tick's counts
     }
 }
@@ -501,6 +521,7 @@ struct ForceArgs {
     // cell key (or DEAD) and the far-mover flag of the next tick's parity
     uint32_t* key_next;
     uint32_t* cell_count; // members per cell of the next pass (one atomicAdd per stored key)
+    uint32_t* row_count;  // members per grid row of the next pass (wave-aggregated)
     uint32_t key_end;    // stale slots [live, key_end) get DEAD keys
     SortFlags* flags;
     uint32_t parity_next;
@@ -856,7 +877,7 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     // potential texels are the ones the goal stencil just touched, so they come from L1/L2)
     if (a.key_next) {
         uint32_t k = DEAD;
-        int32_t cx, cy;
+        int32_t cx = 0, cy = 0;
         if (cell_xy(a.grid, pos, cx, cy) && survives(a.field, pos, a.dest[id])) {
             if (cy >= a.band_lo - 1 && cy <= a.band_hi) {
                 k = (uint32_t)cy * (uint32_t)a.grid.cols + (uint32_t)cx;
@@ -864,7 +885,7 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
             }
         }
         a.key_next[id] = k;
-        if (k != DEAD) atomicAdd(&a.cell_count[k], 1u);
+        count_key(a.cell_count, a.row_count, k != DEAD, k, (uint32_t)cy);
     }
 }
 
@@ -1012,7 +1033,8 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
                                    uint32_t* __restrict__ dest, HaloIn* __restrict__ halo,
                                    FieldView field, GridView grid, int32_t band_lo, int32_t band_hi,
                                    uint32_t parity, SortFlags* __restrict__ flags,
-                                   uint32_t* __restrict__ key, uint32_t* __restrict__ cell_count)
+                                   uint32_t* __restrict__ key, uint32_t* __restrict__ cell_count,
+                                   uint32_t* __restrict__ row_count)
 {
     // thread t < cap: landing slot base - cap + t (the list is right-aligned against base);
     // thread t >= cap: slot gap_end + (t - cap).  Every slot gets a key -- the record's cell
@@ -1042,6 +1064,7 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
         if (k < n_above) src = from_above + PEDONI_HALO_HEADER_WORDS + (size_t)k * PEDONI_HALO_RECORD_WORDS;
     }
     uint32_t kk = DEAD;
+    int32_t cx = 0, cy = 0;
     if (src) {
         v2 p = mk(__uint_as_float(src[0]), __uint_as_float(src[1]));
         uint32_t d = src[5];
@@ -1049,7 +1072,6 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
         vel[at] = make_float2(__uint_as_float(src[2]), __uint_as_float(src[3]));
         v0[at] = __uint_as_float(src[4]);
         dest[at] = d;
-        int32_t cx, cy;
         if (cell_xy(grid, p, cx, cy) && survives(field, p, d)) {
             if (cy >= band_lo - 1 && cy <= band_hi) {
                 kk = (uint32_t)cy * (uint32_t)grid.cols + (uint32_t)cx;
@@ -1060,7 +1082,7 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
         }
     }
     key[at] = kk;
-    if (kk != DEAD) atomicAdd(&cell_count[kk], 1u);
+    count_key(cell_count, row_count, kk != DEAD, kk, (uint32_t)cy);
 }
 
 } // namespace pedoni

@@ -79,6 +79,7 @@ struct PedoniModel {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t side_stream = nullptr;      // interior rows of a split sharded tick
     hipEvent_t ev_sorted = nullptr, ev_interior = nullptr;
+    hipEvent_t ev_tick[2] = {nullptr, nullptr}; // pedoni_hip_tick: device time of update_states
     PedoniOptions opt{};
     float size_x = 0, size_y = 0;
     Rng rng{12345};
@@ -119,12 +120,8 @@ struct PedoniModel {
     uint32_t scan_cap = 0;
     uint32_t* d_block_sums = nullptr;
     uint32_t block_sums_cap = 0;
-    unsigned long long* d_scan_words = nullptr; // single-pass scan: one status word per tile
-    uint32_t scan_words_cap = 0;
-    uint32_t* d_scan_ticket = nullptr;
-    uint32_t scan_epoch = 0;
-    bool scan3 = false;                         // PEDONI_SCAN3=1: three-launch scan
-    uint32_t* d_live = nullptr; // device: live agent count
+    uint32_t* d_row_count = nullptr; // members per grid row (top level of the row scan)
+    uint32_t* d_live = nullptr; // device: [0] live agent count (absolute end index), [1] sticky status word
     uint32_t* h_pinned = nullptr;
     float2* d_acc = nullptr;
     uint32_t acc_cap = 0;
@@ -152,6 +149,15 @@ struct PedoniModel {
     bool no_fuse_key = false;  // PEDONI_NO_FUSE_KEY=1: standalone K_KEY every tick
     bool xcd_remap = true;     // PEDONI_NO_XCD_REMAP=1: hardware block order
     int force_slots = 6;       // PEDONI_FORCE_SLOTS: candidates per lane per batch (6 or 8)
+
+    // steady-state tick pair captured as a hipGraph (pedoni_hip_tick_n); see tick_graph()
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_valid = false;
+    bool use_graph = true;     // PEDONI_NO_GRAPH=1: always launch eagerly
+    uint32_t graph_n_upper = 0, graph_base = 0;
+    int graph_pv = 0, graph_vd = 0, graph_cs = 0, graph_sk = 0;
+    uint32_t graph_parity = 0;
+    hipStream_t graph_stream = nullptr;
 
     // profiling
     uint32_t profile_mask = 0;
@@ -220,91 +226,109 @@ template <typename T> int dev_alloc(T** p, size_t n)
     return PEDONI_OK;
 }
 
+// Grows the agent arrays.  Every new buffer is allocated before anything is released, so a
+// failed allocation leaves the model exactly as it was (and leaks nothing).
 int ensure_capacity(PedoniModel* m, uint32_t need)
 {
     if (need <= m->cap) return PEDONI_OK;
     uint64_t nc = std::max<uint64_t>(m->cap ? m->cap : 1024, 1024);
     while (nc < need) nc *= 2;
     if (nc > 0xfffffff0ull) return fail(PEDONI_E_INVALID, "agent capacity exceeds 2^32");
-    uint32_t ncap = (uint32_t)nc;
+    const uint32_t ncap = (uint32_t)nc;
+    const bool per_agent_scan = !m->opt.use_neighbor_grid; // the scan runs over per-agent flags
+    const uint32_t nscan = ncap + 1, nsums = (nscan + SCAN_TILE - 1) / SCAN_TILE + 1;
 
-    float2 *npos[2], *nvel[2];
-    float* nv0[2];
-    uint32_t* ndest[2];
-    for (int k = 0; k < 2; ++k) {
-        TRY(dev_alloc(&npos[k], ncap));
-        TRY(dev_alloc(&nvel[k], ncap));
-        TRY(dev_alloc(&nv0[k], ncap));
-        TRY(dev_alloc(&ndest[k], ncap));
+    std::vector<void*> fresh;
+    auto grab = [&](auto** p, size_t n) -> int {
+        int rc = dev_alloc(p, n);
+        if (rc == PEDONI_OK) fresh.push_back((void*)*p);
+        return rc;
+    };
+    float2 *npos[2] = {nullptr, nullptr}, *nvel[2] = {nullptr, nullptr};
+    float* nv0[2] = {nullptr, nullptr};
+    uint32_t *ndest[2] = {nullptr, nullptr}, *nskey[2] = {nullptr, nullptr};
+    uint32_t *nkey = nullptr, *nslots = nullptr, *nscan_in = nullptr, *ncs0 = nullptr, *nblock_sums = nullptr;
+    int rc = PEDONI_OK;
+    for (int k = 0; k < 2 && rc == PEDONI_OK; ++k) {
+        rc = grab(&npos[k], ncap);
+        if (rc == PEDONI_OK) rc = grab(&nvel[k], ncap);
+        if (rc == PEDONI_OK) rc = grab(&nv0[k], ncap);
+        if (rc == PEDONI_OK) rc = grab(&ndest[k], ncap);
+        if (rc == PEDONI_OK) rc = grab(&nskey[k], ncap);
     }
-    if (m->n_upper) {
-        size_t n = m->n_upper;
-        HIP_TRY(hipMemcpyAsync(npos[m->pv], m->d_pos[m->pv], n * sizeof(float2),
-                               hipMemcpyDeviceToDevice, m->stream));
-        HIP_TRY(hipMemcpyAsync(nvel[m->pv], m->d_vel[m->pv], n * sizeof(float2),
-                               hipMemcpyDeviceToDevice, m->stream));
-        HIP_TRY(hipMemcpyAsync(nv0[m->vd], m->d_v0[m->vd], n * sizeof(float),
-                               hipMemcpyDeviceToDevice, m->stream));
-        HIP_TRY(hipMemcpyAsync(ndest[m->vd], m->d_dest[m->vd], n * sizeof(uint32_t),
-                               hipMemcpyDeviceToDevice, m->stream));
+    if (rc == PEDONI_OK) rc = grab(&nkey, ncap);
+    if (rc == PEDONI_OK) rc = grab(&nslots, ncap);
+    if (per_agent_scan) {
+        if (rc == PEDONI_OK) rc = grab(&nscan_in, nscan);
+        if (rc == PEDONI_OK) rc = grab(&ncs0, nscan);
+        if (rc == PEDONI_OK) rc = grab(&nblock_sums, nsums);
     }
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    auto copy_over = [&]() -> int {
+        if (!m->n_upper) return PEDONI_OK;
+        const size_t n = m->n_upper;
+        HIP_TRY(hipMemcpyAsync(npos[m->pv], m->d_pos[m->pv], n * sizeof(float2), hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(nvel[m->pv], m->d_vel[m->pv], n * sizeof(float2), hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(nv0[m->vd], m->d_v0[m->vd], n * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(ndest[m->vd], m->d_dest[m->vd], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        return PEDONI_OK;
+    };
+    if (rc == PEDONI_OK) rc = copy_over();
+    if (rc != PEDONI_OK) {
+        for (void* p : fresh) hipFree(p);
+        return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(m->stream)); // nothing in flight still reads the old arrays
     for (int k = 0; k < 2; ++k) {
         hipFree(m->d_pos[k]); hipFree(m->d_vel[k]); hipFree(m->d_v0[k]); hipFree(m->d_dest[k]);
+        hipFree(m->d_skey[k]);
         m->d_pos[k] = npos[k]; m->d_vel[k] = nvel[k]; m->d_v0[k] = nv0[k]; m->d_dest[k] = ndest[k];
+        m->d_skey[k] = nskey[k];
     }
     hipFree(m->d_key); hipFree(m->d_slots);
-    hipFree(m->d_skey[0]); hipFree(m->d_skey[1]);
-    TRY(dev_alloc(&m->d_key, ncap));
-    TRY(dev_alloc(&m->d_slots, ncap));
-    TRY(dev_alloc(&m->d_skey[0], ncap));
-    TRY(dev_alloc(&m->d_skey[1], ncap));
+    m->d_key = nkey;
+    m->d_slots = nslots;
+    if (per_agent_scan) {
+        hipFree(m->d_scan_in); hipFree(m->d_cs[0]); hipFree(m->d_block_sums);
+        m->d_scan_in = nscan_in;
+        m->d_cs[0] = ncs0;
+        m->d_block_sums = nblock_sums;
+        m->scan_cap = nscan;
+        m->block_sums_cap = nsums;
+    }
     m->have_old = false; // the per-agent old-cell array did not survive the reallocation
     m->keys_valid = false;
+    m->graph_valid = false;
     m->cap = ncap;
-
-    if (!m->opt.use_neighbor_grid) {
-        // the scan runs over per-agent flags
-        hipFree(m->d_scan_in); hipFree(m->d_cs[0]); hipFree(m->d_block_sums);
-        m->scan_cap = ncap + 1;
-        TRY(dev_alloc(&m->d_scan_in, m->scan_cap));
-        TRY(dev_alloc(&m->d_cs[0], m->scan_cap));
-        m->block_sums_cap = (m->scan_cap + SCAN_TILE - 1) / SCAN_TILE + 1;
-        TRY(dev_alloc(&m->d_block_sums, m->block_sums_cap));
-    }
     return PEDONI_OK;
 }
 
-// exclusive scan of in[0..n) -> out[0..n) (+ base), total -> out[n] and d_live
+// exclusive scan of in[0..n) -> out[0..n) (+ base), total -> out[n] and d_live: the
+// three-launch form, used by the no-grid option path (per-agent survivor flags)
 int run_scan(PedoniModel* m, uint32_t* in, uint32_t n, int zero_input, uint32_t* out)
 {
     Timed t(m, PEDONI_K_SCAN);
     if (t.rc) return t.rc;
     uint32_t n_blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (n_blocks == 0) n_blocks = 1;
-    if (!m->scan3 && n_blocks <= 4096) {
-        if (m->scan_words_cap < n_blocks) {
-            hipFree(m->d_scan_words);
-            m->d_scan_words = nullptr;
-            uint32_t cap = std::max(n_blocks * 2, 1024u);
-            TRY(dev_alloc(&m->d_scan_words, cap));
-            HIP_TRY(hipMemsetAsync(m->d_scan_words, 0, (size_t)cap * sizeof(unsigned long long), m->stream));
-            m->scan_words_cap = cap;
-        }
-        m->scan_epoch = (m->scan_epoch + 1) & 0x3fffffffu;
-        if (m->scan_epoch == 0) m->scan_epoch = 1;          // 0 = "never written"
-        ScanState st{m->d_scan_words, m->d_scan_ticket};
-        hipLaunchKernelGGL(scan_single_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream, in, n,
-                           m->base, out, m->d_live, zero_input, st, m->scan_epoch);
-        HIP_TRY(hipGetLastError());
-        return PEDONI_OK;
-    }
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream,
                        in, n, m->d_block_sums);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, m->stream, m->d_block_sums,
                        n_blocks, m->base, out + n, m->d_live);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, m->stream,
                        in, n, m->d_block_sums, out, zero_input);
+    HIP_TRY(hipGetLastError());
+    return PEDONI_OK;
+}
+
+// cell counts of grid rows [row0, row1) -> cell_start (neighbor_grid_indices), one launch
+int run_row_scan(PedoniModel* m, int32_t row0, int32_t row1, uint32_t* out, uint32_t limit)
+{
+    Timed t(m, PEDONI_K_SCAN);
+    if (t.rc) return t.rc;
+    hipLaunchKernelGGL(scan_rows_kernel, dim3((uint32_t)(row1 - row0)), dim3(SCAN_THREADS), 0, m->stream,
+                       m->d_scan_in, m->d_row_count, row0, m->grid.cols, m->base, out, m->d_live, limit,
+                       m->d_live + 1);
     HIP_TRY(hipGetLastError());
     return PEDONI_OK;
 }
@@ -338,8 +362,6 @@ int sort_despawn(PedoniModel* m)
         const BandView band{m->band_lo, m->band_hi, m->halo_cap ? 1 : 0};
         // a band only ever touches the cells of rows lo-1 .. hi: scan just those
         const int32_t row0 = std::max(m->band_lo - 1, 0), row1 = std::min(m->band_hi + 1, m->grid.rows);
-        const uint32_t c0 = (uint32_t)row0 * (uint32_t)m->grid.cols;
-        const uint32_t n_scan = (uint32_t)(row1 - row0) * (uint32_t)m->grid.cols;
         SoA soa{m->d_pos[src], m->d_vel[src], m->d_v0[vsrc], m->d_dest[vsrc],
                 m->d_pos[dst], m->d_vel[dst], m->d_v0[vdst], m->d_dest[vdst], m->d_skey[sk_new]};
         {
@@ -348,14 +370,17 @@ int sort_despawn(PedoniModel* m)
             if (!m->keys_valid || force_general) {
                 // every stored agent needs its key (and its cell's count: drop what a fused
                 // update may already have accumulated for keys that are now recomputed)
-                if (m->counts_dirty)
+                if (m->counts_dirty) {
                     HIP_TRY(hipMemsetAsync(m->d_scan_in, 0, (size_t)(m->n_cells + 1) * sizeof(uint32_t),
                                            m->stream));
+                    HIP_TRY(hipMemsetAsync(m->d_row_count, 0, (size_t)(m->grid.rows + 1) * sizeof(uint32_t),
+                                           m->stream));
+                }
                 hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0, m->stream,
                                    m->d_pos[src], m->d_dest[vsrc], i0, n_total, m->base, m->d_live,
                                    m->gap_end, m->d_halo, m->field, m->grid, m->band_lo, m->band_hi,
                                    m->d_skey[sk_old], force_general, parity, m->d_flags, m->d_key,
-                                   m->d_scan_in);
+                                   m->d_scan_in, m->d_row_count);
             } else {
                 // own agents got their keys (and counts) from the last update_states; only agents
                 // stored since then are keyed here (exchanged lists: by halo_unpack_kernel)
@@ -364,16 +389,16 @@ int sort_despawn(PedoniModel* m)
                                        m->stream, m->d_pos[src], m->d_dest[vsrc], i0, m->base, m->base,
                                        m->d_live, m->gap_end, m->d_halo, m->field, m->grid, m->band_lo,
                                        m->band_hi, m->d_skey[sk_old], 0, parity, m->d_flags, m->d_key,
-                                       m->d_scan_in);
+                                       m->d_scan_in, m->d_row_count);
                 if (n_total > m->gap_end && !m->halo_keys_done)
                     hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_total - m->gap_end, bs)), dim3(bs),
                                        0, m->stream, m->d_pos[src], m->d_dest[vsrc], m->gap_end, n_total,
                                        m->base, m->d_live, m->gap_end, m->d_halo, m->field, m->grid,
                                        m->band_lo, m->band_hi, m->d_skey[sk_old], 0, parity, m->d_flags,
-                                       m->d_key, m->d_scan_in);
+                                       m->d_key, m->d_scan_in, m->d_row_count);
             }
         }
-        TRY(run_scan(m, m->d_scan_in + c0, n_scan, /*zero_input=*/1, m->d_cs[cs_new] + c0));
+        TRY(run_row_scan(m, row0, row1, m->d_cs[cs_new], n_total));
         m->counts_dirty = false;
         {
             Timed t(m, PEDONI_K_SLOT);
@@ -381,7 +406,8 @@ int sort_despawn(PedoniModel* m)
             hipLaunchKernelGGL(place_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
                                m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
-                               (m->halo_cap || m->n_spawners) ? m->d_halo : nullptr);
+                               (m->halo_cap || m->n_spawners) ? m->d_halo : nullptr, m->d_row_count, row0,
+                               row1, m->d_live + 1);
         }
         {
             Timed t(m, PEDONI_K_REORDER);
@@ -457,6 +483,7 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
                       m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
     a.key_next = fuse ? m->d_key : nullptr;
     a.cell_count = m->d_scan_in;
+    a.row_count = m->d_row_count;
     a.key_end = m->n_upper;
     a.flags = m->d_flags;
     a.parity_next = m->tick_parity & 1u;
@@ -529,12 +556,27 @@ int update_states(PedoniModel* m)
     return PEDONI_OK;
 }
 
+// the sticky device status word (kernels.hpp STATUS_*): no host read of device state
+// succeeds while a bit is set
+int check_status(uint32_t status)
+{
+    if (status & STATUS_SCAN_MISMATCH)
+        return fail(PEDONI_E_HIP, "device status: a grid row's cell counts do not add up to its row count "
+                                  "(neighbor_grid_indices would be wrong)");
+    if (status & STATUS_LIVE_OVERFLOW)
+        return fail(PEDONI_E_CAPACITY, "device status: more live agents than the host's bound of the arrays "
+                                       "(received lists larger than the reserved capacity?)");
+    if (status) return fail(PEDONI_E_HIP, "device status word is set: " + std::to_string(status));
+    return PEDONI_OK;
+}
+
 int sync_live_count(PedoniModel* m, uint32_t* out)
 {
-    HIP_TRY(hipMemcpyAsync(m->h_pinned, m->d_live, sizeof(uint32_t), hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(m->h_pinned, m->d_live, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost,
                            m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     uint32_t live = m->h_pinned[0]; // absolute end index
+    TRY(check_status(m->h_pinned[1]));
     if (m->n_spawners) { // a tick that spawned more than max_per_tick must not pass silently
         HaloIn h{};
         HIP_TRY(hipMemcpy(&h, m->d_halo, sizeof h, hipMemcpyDeviceToHost));
@@ -664,10 +706,10 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
         m->no_fuse_key = nf && nf[0] == '1';
         const char* nx = std::getenv("PEDONI_NO_XCD_REMAP");
         m->xcd_remap = !(nx && nx[0] == '1');
+        const char* ng = std::getenv("PEDONI_NO_GRAPH");
+        m->use_graph = !(ng && ng[0] == '1');
         const char* fsl = std::getenv("PEDONI_FORCE_SLOTS");
         if (fsl) m->force_slots = std::atoi(fsl);
-        const char* s3 = std::getenv("PEDONI_SCAN3");
-        m->scan3 = s3 && s3[0] == '1';
     }
     *out = nullptr;
 
@@ -732,8 +774,8 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
             C_TRY(dev_alloc(&m->d_cs[k], m->scan_cap));
             C_HIP(hipMemset(m->d_cs[k], 0, (size_t)m->scan_cap * sizeof(uint32_t)));
         }
-        m->block_sums_cap = (m->scan_cap + SCAN_TILE - 1) / SCAN_TILE + 1;
-        C_TRY(dev_alloc(&m->d_block_sums, m->block_sums_cap));
+        C_TRY(dev_alloc(&m->d_row_count, (size_t)m->grid.rows + 1));
+        C_HIP(hipMemset(m->d_row_count, 0, ((size_t)m->grid.rows + 1) * sizeof(uint32_t)));
     }
     m->band_lo = 0;
     m->band_hi = opt->use_neighbor_grid ? m->grid.rows : 0;
@@ -742,8 +784,6 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
     C_HIP(hipMemset(m->d_live, 0, 4 * sizeof(uint32_t)));
     C_TRY(dev_alloc(&m->d_flags, 1));
     C_HIP(hipMemset(m->d_flags, 0, sizeof(SortFlags)));
-    C_TRY(dev_alloc(&m->d_scan_ticket, 4));
-    C_HIP(hipMemset(m->d_scan_ticket, 0, 4 * sizeof(uint32_t)));
     C_TRY(dev_alloc(&m->d_halo, 1));
     C_HIP(hipMemset(m->d_halo, 0, sizeof(HaloIn)));
     C_HIP(hipHostMalloc((void**)&m->h_pinned, 16 * sizeof(uint32_t), hipHostMallocDefault));
@@ -769,7 +809,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     hipFree(m->d_skey[0]); hipFree(m->d_skey[1]); hipFree(m->d_flags);
     hipFree(m->d_live); hipFree(m->d_acc); hipFree(m->d_halo);
     hipFree(m->d_spawners); hipFree(m->d_spawn_state);
-    hipFree(m->d_scan_words); hipFree(m->d_scan_ticket);
+    hipFree(m->d_row_count);
     if (m->h_pinned) hipHostFree(m->h_pinned);
     hipFree(m->d_distance_map);
     for (float* p : m->d_pot) hipFree(p);
@@ -778,6 +818,8 @@ void pedoni_hip_destroy(PedoniModel* m)
     if (m->side_stream) { hipStreamSynchronize(m->side_stream); hipStreamDestroy(m->side_stream); }
     if (m->ev_sorted) hipEventDestroy(m->ev_sorted);
     if (m->ev_interior) hipEventDestroy(m->ev_interior);
+    for (hipEvent_t e : m->ev_tick) if (e) hipEventDestroy(e);
+    if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
     if (m->own_stream) hipStreamDestroy(m->own_stream);
     delete m;
 }
@@ -845,13 +887,78 @@ int device_spawn(PedoniModel* m)
 }
 } // namespace
 
+namespace {
+// Steady state (no agents appended, no exchange, no device spawning, keys fused by the last
+// update): a tick is scan -> place -> reorder -> force with every branch decided on the
+// device, and after TWO ticks every ping-pong index of the host is back where it was.  That
+// pair is captured once as a hipGraph and replayed: one graph launch instead of eight kernel
+// launches, which is what bounds the small configurations (C2: 1e5 agents) -- the kernels are
+// the same, so the results are too.  Anything that changes a baked-in argument (host bound,
+// buffers, stream, options) invalidates the capture.
+bool graphable(const PedoniModel* m)
+{
+    return m->use_graph && m->stream != nullptr && m->opt.use_neighbor_grid && !m->force_simple && !m->sort_general &&
+           !m->no_fuse_key && !m->n_spawners && !m->halo_cap && !m->profile_mask && m->have_old &&
+           m->keys_valid && !m->sorted && m->gap_end == m->n_upper && m->n_upper > m->base &&
+           m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
+}
+
+int tick_graph_pair(PedoniModel* m)
+{
+    const bool match = m->graph_valid && m->graph_exec && m->graph_n_upper == m->n_upper &&
+                       m->graph_base == m->base && m->graph_pv == m->pv && m->graph_vd == m->vd &&
+                       m->graph_cs == m->cs && m->graph_sk == m->sk &&
+                       m->graph_parity == (m->tick_parity & 1u) && m->graph_stream == m->stream;
+    if (!match) {
+        if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+        m->graph_valid = false;
+        const uint32_t n_upper = m->n_upper, base = m->base, parity = m->tick_parity & 1u;
+        const int pv = m->pv, vd = m->vd, cs = m->cs, sk = m->sk;
+        HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+        int rc = PEDONI_OK;
+        for (int t = 0; t < 2 && rc == PEDONI_OK; ++t) {
+            rc = sort_despawn(m);
+            if (rc == PEDONI_OK) rc = update_states(m);
+        }
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamEndCapture(m->stream, &graph);
+        if (rc != PEDONI_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return fail(PEDONI_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        e = hipGraphInstantiate(&m->graph_exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) { m->graph_exec = nullptr; return fail(PEDONI_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+        // the capture ran the host bookkeeping of two ticks: the indices are back at the key
+        if (m->pv != pv || m->vd != vd || m->cs != cs || m->sk != sk || (m->tick_parity & 1u) != parity ||
+            m->n_upper != n_upper)
+            return fail(PEDONI_E_HIP, "tick graph: host state did not return after two ticks");
+        m->graph_n_upper = n_upper; m->graph_base = base; m->graph_pv = pv; m->graph_vd = vd;
+        m->graph_cs = cs; m->graph_sk = sk; m->graph_parity = parity; m->graph_stream = m->stream;
+        m->graph_valid = true;
+    }
+    HIP_TRY(hipGraphLaunch(m->graph_exec, m->stream));
+    // host state after a pair of ticks == before it (see above); the flags the eager path
+    // would have left: keys fused, counts pending, order not sorted
+    m->keys_valid = true;
+    m->counts_dirty = true;
+    m->sorted = false;
+    return PEDONI_OK;
+}
+} // namespace
+
 int pedoni_hip_tick_n(PedoniModel* m, uint32_t steps)
 {
     TRY(bind(m));
-    for (uint32_t s = 0; s < steps; ++s) {
+    uint32_t s = 0;
+    while (s < steps) {
+        if (steps - s >= 2 && graphable(m)) {
+            TRY(tick_graph_pair(m));
+            s += 2;
+            continue;
+        }
         if (m->n_spawners) TRY(device_spawn(m));
         TRY(sort_despawn(m));
         TRY(update_states(m));
+        s += 1;
     }
     return PEDONI_OK;
 }
@@ -920,24 +1027,26 @@ int pedoni_hip_tick(PedoniModel* m, PedoniStepMetrics* metrics)
 {
     TRY(bind(m));
     using clk = std::chrono::steady_clock;
+    if (!m->ev_tick[0]) {
+        HIP_TRY(hipEventCreate(&m->ev_tick[0]));
+        if (hipEventCreate(&m->ev_tick[1]) != hipSuccess) {
+            hipEventDestroy(m->ev_tick[0]);
+            m->ev_tick[0] = nullptr;
+            return fail(PEDONI_E_HIP, "hipEventCreate failed");
+        }
+    }
     HIP_TRY(hipStreamSynchronize(m->stream));
     auto t0 = clk::now();
     TRY(sort_despawn(m));
     HIP_TRY(hipStreamSynchronize(m->stream));
     auto t1 = clk::now();
-    hipEvent_t ea = nullptr, eb = nullptr;
-    HIP_TRY(hipEventCreate(&ea));
-    HIP_TRY(hipEventCreate(&eb));
-    HIP_TRY(hipEventRecord(ea, m->stream));
-    int rc = update_states(m);
-    hipEventRecord(eb, m->stream);
-    hipStreamSynchronize(m->stream);
+    HIP_TRY(hipEventRecord(m->ev_tick[0], m->stream));
+    TRY(update_states(m));
+    HIP_TRY(hipEventRecord(m->ev_tick[1], m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
     auto t2 = clk::now();
     float ms = -1.0f;
-    hipEventElapsedTime(&ms, ea, eb);
-    hipEventDestroy(ea);
-    hipEventDestroy(eb);
-    if (rc) return rc;
+    if (hipEventElapsedTime(&ms, m->ev_tick[0], m->ev_tick[1]) != hipSuccess) ms = -1.0f;
     if (metrics) {
         uint32_t live = 0;
         TRY(sync_live_count(m, &live));
@@ -1169,18 +1278,24 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
     TRY(bind(m));
     if (cap_each != m->halo_cap || cap_each == 0)
         return fail(PEDONI_E_INVALID, "halo_unpack: cap_each differs from set_band's halo capacity");
-    // The list from above lands behind everything stored, so the host's bound of the end
-    // of the arrays grows by cap_each per tick although the true count (on the device) does
-    // not.  Re-read the count every 16 ticks -- one stream sync per 16 ticks, ~1.5 us per
-    // tick amortised -- so launches never cover more than ~7 % idle threads; and always
-    // before the arrays would have to grow.
-    if (m->gap_end == m->n_upper &&
-        (++m->ticks_since_tighten >= 16 || (uint64_t)m->n_upper + cap_each > m->cap)) {
+    // agents appended by the host since the last pass would count as neither own nor received
+    // (the above list starts at gap_end): they must go through a pass first
+    if (m->gap_end != m->n_upper)
+        return fail(PEDONI_E_INVALID, "halo_unpack: host-appended agents are pending; run sort_despawn after append");
+    // The received lists land outside the own agents ([base - n, base) and behind everything
+    // stored), and after the sort every live agent -- own, from below, from above -- sits in
+    // [base, live): the host's bound of the end of the arrays must grow by the capacity of
+    // EVERY list received (the slots behind the stored agents are keyed even with no band
+    // above), although the true count (on the device) barely changes.  Re-read the count every
+    // 8 ticks -- one stream sync per 8 ticks -- so launches never cover more than ~7 % idle
+    // threads; and always before the arrays would have to grow.
+    const uint32_t grow = cap_each * std::max(1u, (from_below_dev ? 1u : 0u) + (from_above_dev ? 1u : 0u));
+    if (++m->ticks_since_tighten >= 8 || (uint64_t)m->n_upper + grow > m->cap) {
         uint32_t live = 0;
         TRY(sync_live_count(m, &live));
         m->ticks_since_tighten = 0;
     }
-    TRY(ensure_capacity(m, m->n_upper + cap_each));
+    TRY(ensure_capacity(m, m->n_upper + grow));
     const uint32_t words_each = PEDONI_HALO_HEADER_WORDS + cap_each * PEDONI_HALO_RECORD_WORDS;
     // a rank's buffer is [down list][up list]: the band below sends us its UP list, the band
     // above its DOWN list
@@ -1191,11 +1306,12 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
     hipLaunchKernelGGL(halo_unpack_kernel, dim3(blocks_for(2 * cap_each, 256)), dim3(256), 0,
                        m->stream, below, above, cap_each, m->base, m->n_upper, m->d_pos[m->pv],
                        m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_halo, m->field, m->grid,
-                       m->band_lo, m->band_hi, m->tick_parity & 1u, m->d_flags, m->d_key, m->d_scan_in);
+                       m->band_lo, m->band_hi, m->tick_parity & 1u, m->d_flags, m->d_key, m->d_scan_in,
+                       m->d_row_count);
     HIP_TRY(hipGetLastError());
     m->counts_dirty = true;
     m->gap_end = m->n_upper;      // the above list starts here
-    m->n_upper += cap_each;       // host bound; the device knows the true count
+    m->n_upper += grow;           // host bound; the device knows the true count
     m->halo_keys_done = true;     // the exchanged agents already carry their keys
     m->sorted = false;
     return PEDONI_OK;
@@ -1204,6 +1320,7 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
 int pedoni_hip_halo_tick(PedoniModel* m, const void* from_below_dev, const void* from_above_dev,
                          void* send_dev, uint32_t cap_each)
 {
+    if (!send_dev) return fail(PEDONI_E_INVALID, "halo_tick: null send buffer");
     TRY(pedoni_hip_halo_unpack(m, from_below_dev, from_above_dev, cap_each));
     TRY(sort_despawn(m));
     TRY(update_states(m));
@@ -1218,9 +1335,9 @@ int pedoni_hip_halo_tick(PedoniModel* m, const void* from_below_dev, const void*
 int pedoni_hip_halo_tick_begin(PedoniModel* m, const void* from_below_dev, const void* from_above_dev,
                                void* send_dev, uint32_t cap_each)
 {
+    if (!send_dev) return fail(PEDONI_E_INVALID, "halo_tick_begin: null send buffer");
     TRY(pedoni_hip_halo_unpack(m, from_below_dev, from_above_dev, cap_each));
     TRY(sort_despawn(m));
-    if (!send_dev) return fail(PEDONI_E_INVALID, "halo_tick_begin: null send buffer");
     if (m->band_hi - m->band_lo < 6 || m->force_simple) {
         // band too thin to split: whole tick now, nothing left for _end
         TRY(update_states(m));
@@ -1258,12 +1375,14 @@ int pedoni_hip_owned_count(PedoniModel* m, int32_t* count)
         return pedoni_hip_get_pedestrian_count(m, count);
     uint32_t lo = 0, hi = 0;
     HaloIn h{};
+    HIP_TRY(hipMemcpyAsync(m->h_pinned + 2, m->d_live + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(&lo, m->d_cs[m->cs] + (size_t)m->band_lo * m->grid.cols, sizeof(uint32_t),
                            hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(&hi, m->d_cs[m->cs] + (size_t)m->band_hi * m->grid.cols, sizeof(uint32_t),
                            hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(&h, m->d_halo, sizeof(HaloIn), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    TRY(check_status(m->h_pinned[2]));
     if (h.error & 1u) return fail(PEDONI_E_CAPACITY, "halo list overflow: raise the halo capacity");
     if (h.error & 2u)
         return fail(PEDONI_E_INVALID, "an agent left its band by more than one grid row in one tick");
@@ -1272,6 +1391,14 @@ int pedoni_hip_owned_count(PedoniModel* m, int32_t* count)
     if (h.error & 8u)
         return fail(PEDONI_E_CAPACITY, "a tick spawned more agents than max_per_tick");
     *count = (int32_t)(hi - lo);
+    return PEDONI_OK;
+}
+
+int pedoni_hip_debug_set_status(PedoniModel* m, uint32_t status_word)
+{
+    TRY(bind(m));
+    HIP_TRY(hipMemcpyAsync(m->d_live + 1, &status_word, sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
     return PEDONI_OK;
 }
 
@@ -1406,17 +1533,22 @@ extern "C" int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mod
     HIP_TRY(hipSetDevice(device));
     if (n == 0) return PEDONI_OK;
     float *da = nullptr, *db = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc((void**)&da, n * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&db, n * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&dout, n * sizeof(float)));
-    HIP_TRY(hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice));
-    if (b) HIP_TRY(hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice));
-    if (math_mode == PEDONI_MATH_FAST)
-        hipLaunchKernelGGL(selftest_kernel<1>, dim3((n + 255) / 256), dim3(256), 0, 0, op, da, db, dout, n);
-    else
-        hipLaunchKernelGGL(selftest_kernel<0>, dim3((n + 255) / 256), dim3(256), 0, 0, op, da, db, dout, n);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost));
+    int rc = PEDONI_OK;
+    if (hipMalloc((void**)&da, n * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&db, n * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&dout, n * sizeof(float)) != hipSuccess ||
+        hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        (b && hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess))
+        rc = fail(PEDONI_E_HIP, "selftest_math: device allocation / copy failed");
+    if (rc == PEDONI_OK) {
+        if (math_mode == PEDONI_MATH_FAST)
+            hipLaunchKernelGGL(selftest_kernel<1>, dim3((n + 255) / 256), dim3(256), 0, 0, op, da, db, dout, n);
+        else
+            hipLaunchKernelGGL(selftest_kernel<0>, dim3((n + 255) / 256), dim3(256), 0, 0, op, da, db, dout, n);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(PEDONI_E_HIP, "selftest_math: launch / copy failed");
+    }
     hipFree(da); hipFree(db); hipFree(dout);
-    return PEDONI_OK;
+    return rc;
 }

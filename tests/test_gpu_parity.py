@@ -203,7 +203,16 @@ def test_tick_n_without_host_sync_keeps_parity_through_despawns(hip, oracle):
 # ---- C2-style: random obstacles, injected crowd, per step from identical state -----------
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 5000, 100_000])
 def test_random_crowd_per_step_parity(hip, oracle, n):
-    sc = random_obstacle_scenario(200.0, 300 if n < 100_000 else 1000)
+    # n = 100 000 is BASELINE.json configs[1] (C2) on the file it names: the geometry of the
+    # reference's scenarios/random.toml (200 x 200 m, 4 waypoints, 1004 obstacles; committed as
+    # the data fixture tests/golden/scenarios/random.toml) with 100 000 injected agents
+    if n == 100_000:
+        from helpers import GOLDEN
+        from pedoni_amd import scenario as scn
+        sc = scn.load(GOLDEN / "scenarios" / "random.toml")
+        assert len(sc.obstacles) == 1004 and len(sc.waypoints) == 4 and sc.field.size == (200.0, 200.0)
+    else:
+        sc = random_obstacle_scenario(200.0, 300)
     field = oracle_field(oracle, sc)
     pos, dest, v0, vel = inject_crowd(field, sc.field.size, n, 4, seed=100 + n)
     cpu = oracle.OracleModel(sc.field.size)

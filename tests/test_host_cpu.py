@@ -175,3 +175,102 @@ def test_cpp_field_builder_equals_oracle_restatement(oracle, name):
 def test_field_shape_is_ceil_of_size_over_unit():
     f = host.Field.build((5.1, 3.0), 0.25, np.zeros((0, 5)), [[1, 1, 1, 2, 1.0]])
     assert f.shape == (12, 21)
+
+
+# ---- the line burner (field.rs:42-88 -> geo-rasterize 0.1.2): PARITY UNPINNED ---------------
+def _exact_traversal(verts_cells, rows, cols):
+    """Third, independent statement of "every pixel a closed outline touches": an exact
+    parametric walk of each edge over the unit pixel grid in float64 (Amanatides-Woo), written
+    here in the test, sharing nothing with the oracle's or the product's GDAL-style burner."""
+    import math
+    mask = np.zeros((rows, cols), bool)
+
+    def put(c, r):
+        if 0 <= c < cols and 0 <= r < rows:
+            mask[r, c] = True
+    v = np.asarray(verts_cells, np.float32).astype(np.float64).reshape(-1, 2)
+    for i in range(len(v)):
+        (x0, y0), (x1, y1) = v[i], v[(i + 1) % len(v)]
+        dx, dy = x1 - x0, y1 - y0
+        c, r = math.floor(x0), math.floor(y0)
+        ce, re_ = math.floor(x1), math.floor(y1)
+        sc, sr = (1 if dx > 0 else -1), (1 if dy > 0 else -1)
+        tx = (((c + 1) if dx > 0 else c) - x0) / dx if dx != 0 else math.inf
+        ty = (((r + 1) if dy > 0 else r) - y0) / dy if dy != 0 else math.inf
+        ddx = abs(1.0 / dx) if dx != 0 else math.inf
+        ddy = abs(1.0 / dy) if dy != 0 else math.inf
+        put(c, r)
+        for _ in range(abs(ce - c) + abs(re_ - r) + 4):
+            if c == ce and r == re_:
+                break
+            if tx < ty:
+                tx += ddx
+                c += sc
+            else:
+                ty += ddy
+                r += sr
+            put(c, r)
+    return mask
+
+
+def _outline_cells(seg, unit=0.25):
+    """util::line_with_width (util.rs:106-111) in f32, scaled to pixel coordinates."""
+    x0, y0, x1, y1, w = (np.float32(t) for t in seg)
+    dx, dy = x1 - x0, y1 - y0
+    rcp = np.float32(1.0) / np.sqrt(dx * dx + dy * dy, dtype=np.float32)
+    ax, ay = dx * rcp, dy * rcp
+    bx, by = ay * np.float32(0.5) * w, -ax * np.float32(0.5) * w
+    v = np.array([[x0 - bx, y0 - by], [x0 + bx, y0 + by], [x1 + bx, y1 + by], [x1 - bx, y1 - by]], np.float32)
+    return v / np.float32(unit)
+
+
+def test_line_burner_is_all_touched_up_to_corner_ties(oracle):
+    """Product (C++) == oracle (C) on the obstacle mask of scenarios/random.toml's 1004
+    obstacles -- both follow geo-rasterize's DOCUMENTED lineage, GDAL's all-touched line burner,
+    so their agreement is a consistency check, not a pin -- and both equal an exact grid
+    traversal written independently here except where an edge passes through a pixel corner or
+    ends on a pixel edge (a handful of cells)."""
+    sc = scn.load(GOLDEN / "scenarios" / "random.toml")
+    got = host.Field.build(sc.field.size, 0.25, sc.obstacle_array(), sc.waypoint_array())
+    want = oracle_field(oracle, sc)
+    assert np.array_equal(got.obstacle_exist, want.obstacle_exist)
+    rows, cols = got.shape
+    exact = np.zeros((rows, cols), bool)
+    exact[0, :] = exact[-1, :] = exact[:, 0] = exact[:, -1] = True       # field.rs:29-32 border
+    for seg in sc.obstacle_array():
+        exact |= _exact_traversal(_outline_cells(seg), rows, cols)
+    diff = int((exact != got.obstacle_exist).sum())
+    assert diff <= 8 and diff / exact.sum() < 2e-4, f"{diff} cells differ from the exact traversal"
+    # every differing cell is 8-adjacent to a cell both forms burn (a corner / end-point tie)
+    both = exact & got.obstacle_exist
+    grown = both.copy()
+    for sy in (-1, 0, 1):
+        for sx in (-1, 0, 1):
+            grown |= np.roll(np.roll(both, sy, 0), sx, 1)
+    assert not ((exact != got.obstacle_exist) & ~grown).any()
+
+
+def test_upstream_test_obstacle_shape_printed_grid(oracle):
+    """field.rs:272-286 `test_obstacle` rasterises (5,3.5)-(5,4.5)-(15,4.5)-(15,3.5) on a 20 x 10
+    grid and only PRINTS it: no expected value exists upstream.  This is the slot for one: the
+    grid below is what this build's burner gives for the closed outline of that shape (upstream
+    passes it as a filled Polygon; for a 1-pixel-high rectangle the outline and the fill of
+    GDAL's rules cover the same pixels).  If the upstream test is ever run, paste its output
+    over `expected` -- until then this pins the build against itself only (parity unpinned)."""
+    expected = [
+        "....................",
+        "....................",
+        "....................",
+        ".....###########....",
+        ".....###########....",
+        "....................",
+        "....................",
+        "....................",
+        "....................",
+        "....................",
+    ]
+    verts = np.array([[5.0, 3.5], [5.0, 4.5], [15.0, 4.5], [15.0, 3.5]], np.float32)
+    mask = oracle.rasterize_outline(verts, 10, 20)
+    grid = ["".join("#" if c else "." for c in row) for row in mask]
+    assert grid == expected, "\n" + "\n".join(grid)
+    assert np.array_equal(_exact_traversal(verts, 10, 20), mask)

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise tools/profile_stalls.sh passes into profiles/TAG_stalls.json.
+
+    tools/stall_summary.py TAG gpurun_out/stalls_TAG
+
+Per kernel: the average of every collected counter over its launches, plus derived shares of
+the wave lifetime (SQ_WAVE_CYCLES, quad-cycles summed over waves): issuing (ACTIVE_INST_ANY),
+parked on s_waitcnt / barrier (WAIT_ANY), issue-stalled (WAIT_INST_ANY).
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def main():
+    tag, out_dir = sys.argv[1], sys.argv[2]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{out_dir}/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {}
+    for k, cs in agg.items():
+        if not k.startswith("pedoni::"):
+            continue
+        d = {c: sum(v) / len(v) for c, v in cs.items()}
+        d["launches_seen"] = max(len(v) for v in cs.values())
+        wc = d.get("SQ_WAVE_CYCLES")
+        if wc:
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                      "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_LDS"):
+                if c in d:
+                    d["share_" + c[3:].lower()] = d[c] / wc
+        if d.get("SQ_WAVES") and wc:
+            d["quad_cycles_per_wave"] = wc / d["SQ_WAVES"]
+        if d.get("SQ_WAVES") and d.get("SQ_INSTS_VALU"):
+            d["valu_insts_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
+        res[k] = d
+    p = ROOT / "profiles" / f"{tag}_stalls.json"
+    p.write_text(json.dumps(res, indent=1, sort_keys=True))
+    for k, d in res.items():
+        if "force" in k:
+            print(k, json.dumps({c: (round(v, 4) if v < 10 else round(v)) for c, v in sorted(d.items())}, indent=1))
+    print("wrote", p)
+
+
+if __name__ == "__main__":
+    main()
