@@ -214,6 +214,49 @@ int pedoni_hip_halo_tick_end(PedoniModel* m);
 /* owned-agent count (excludes ghosts) */
 int pedoni_hip_owned_count(PedoniModel* m, int32_t* count);
 
+/* [ext] the multi-GPU driver below the C-ABI (no reference counterpart; SURVEY 5.8, 8(e);
+ * BASELINE north_star: "per-step RCCL all-gather over xGMI of ghost agents in halo grid
+ * cells").  One process per GPU; a PedoniShard wraps the rank's PedoniModel, owns an RCCL
+ * communicator and drives   exchange -> halo_unpack -> sort/despawn -> update_states ->
+ * halo_pack   every tick on the model's stream, with no host synchronisation per tick.  The
+ * exchange is ONE grouped ncclSend / ncclRecv pair with rank-1 and rank+1 (only neighbours
+ * ever read a band's lists: 2 of the 7 xGMI links, minimal bytes -- SURVEY 5.8 option 1),
+ * issued by this library straight into librccl (resolved with dlopen at first use, so the
+ * library also loads where RCCL is absent).  A Rust / C++ / C host needs nothing else to run
+ * 8 GPUs: distribute the 128-byte id of rank 0 by any channel, create, append the band's
+ * agents, begin, tick_n.
+ *
+ * Band boundaries are grid rows: `row_bounds` holds world + 1 ascending entries, rank r owns
+ * rows [row_bounds[r], row_bounds[r+1]).  pedoni_shard_balanced_bounds cuts the rows so that
+ * every band holds about the same number of AGENTS given the per-row counts (the cell_start
+ * prefix of a sorted crowd), with at least `min_rows` rows per band. */
+typedef struct PedoniShard PedoniShard;
+#define PEDONI_SHARD_ID_BYTES 128
+int pedoni_shard_unique_id(uint8_t id[PEDONI_SHARD_ID_BYTES]);
+int pedoni_shard_balanced_bounds(const uint32_t* row_counts, uint32_t n_rows, int32_t world,
+                                 int32_t min_rows, int32_t* bounds_out /* world + 1 */);
+/* `id` NULL: no communicator (world == 1, or a member of a local group, below).  The model
+ * must hold no agents; it is given the band [row_bounds[rank], row_bounds[rank+1]). */
+int pedoni_shard_create(PedoniModel* m, int32_t rank, int32_t world, const uint8_t* id,
+                        const int32_t* row_bounds, uint32_t halo_cap, PedoniShard** out);
+void pedoni_shard_destroy(PedoniShard* s); /* does not destroy the model */
+/* after the rank's own agents were appended (pedoni_hip_append): first pass + first pack */
+int pedoni_shard_begin(PedoniShard* s);
+int pedoni_shard_tick_n(PedoniShard* s, uint32_t steps);
+int pedoni_shard_owned_count(PedoniShard* s, int32_t* count);
+int pedoni_shard_band(PedoniShard* s, int32_t* row_begin, int32_t* row_end);
+/* a token ring through the very ncclSend / ncclRecv pair the exchange uses (self-addressed at
+ * the outer bands): PEDONI_OK iff both neighbours' tokens arrived */
+int pedoni_shard_selftest(PedoniShard* s);
+/* every `every_ticks` ticks (0 = never) the bands are re-cut from the global per-row agent
+ * counts so that each holds about N / world agents: the rows that change owner travel, full
+ * state, to the neighbour in one grouped send / receive; results stay bit-identical to one GPU */
+int pedoni_shard_set_rebalance(PedoniShard* s, uint32_t every_ticks, uint32_t max_rows_per_step);
+/* G shards of ONE process on one device, the transport replaced by device copies: the same
+ * driver code, testable on a single GPU (tests/test_gpu_shard.py).  Ticks all shards in
+ * lockstep. */
+int pedoni_shard_local_group_tick_n(PedoniShard** shards, uint32_t n_shards, uint32_t steps);
+
 /* [ext] test hook: overwrite the model's sticky device status word (the word the scan and
  * place kernels raise when cell and row counts disagree or the live count exceeds the host's
  * bound of the arrays).  While it is non-zero every read of device state -- get_pedestrian_count,

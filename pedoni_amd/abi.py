@@ -40,6 +40,9 @@ SYMBOLS = [
     "pedoni_hip_owned_count",
     "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_selftest_field", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
     "pedoni_hip_debug_set_status",
+    "pedoni_shard_unique_id", "pedoni_shard_balanced_bounds", "pedoni_shard_create", "pedoni_shard_destroy",
+    "pedoni_shard_begin", "pedoni_shard_tick_n", "pedoni_shard_owned_count", "pedoni_shard_band",
+    "pedoni_shard_selftest", "pedoni_shard_set_rebalance", "pedoni_shard_local_group_tick_n",
 ]
 
 
@@ -96,7 +99,11 @@ class Options:
 
 
 def library_path() -> Path:
-    return _ROOT / "lib" / "libpedoni_hip.so"
+    # PEDONI_HIP_LIB: another build of the SAME library (A/B of compiler flags in tools/); a
+    # path that does not exist fails loudly like the default one
+    import os
+    override = os.environ.get("PEDONI_HIP_LIB")
+    return Path(override) if override else _ROOT / "lib" / "libpedoni_hip.so"
 
 
 def load_library() -> C.CDLL:
@@ -401,3 +408,89 @@ class HipModel:
     def debug_set_status(self, word: int) -> None:
         """Test hook: overwrite the sticky device status word (0 clears it)."""
         _check(self._lib, self._lib.pedoni_hip_debug_set_status(self._h, C.c_uint32(word)))
+
+
+# -- multi-GPU driver below the C-ABI (pedoni_shard_*) ---------------------------------------
+SHARD_ID_BYTES = 128
+
+
+def shard_unique_id() -> bytes:
+    """ncclGetUniqueId on rank 0; hand the 128 bytes to every rank by any channel."""
+    lib = load_library()
+    buf = (C.c_uint8 * SHARD_ID_BYTES)()
+    _check(lib, lib.pedoni_shard_unique_id(buf))
+    return bytes(buf)
+
+
+def balanced_bounds(row_counts, world: int, min_rows: int = 6) -> list:
+    """Row boundaries that give every band about the same number of AGENTS (pure host code)."""
+    lib = load_library()
+    rc = np.ascontiguousarray(row_counts, np.uint32)
+    out = (C.c_int32 * (world + 1))()
+    _check(lib, lib.pedoni_shard_balanced_bounds(rc.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(len(rc)),
+                                                 C.c_int32(world), C.c_int32(min_rows), out))
+    return list(out)
+
+
+class Shard:
+    """One rank's band, driven by the library itself: direct RCCL neighbour exchange (or, with
+    `unique_id=None`, a member of a local group on one device -- see `local_group_tick_n`)."""
+
+    def __init__(self, model: "HipModel", rank: int, world: int, row_bounds: Sequence[int], halo_cap: int,
+                 unique_id: Optional[bytes] = None):
+        self._lib = model._lib
+        self.model, self.rank, self.world = model, rank, world
+        b = (C.c_int32 * (world + 1))(*[int(x) for x in row_bounds])
+        idbuf = None
+        if unique_id is not None:
+            assert len(unique_id) == SHARD_ID_BYTES
+            idbuf = (C.c_uint8 * SHARD_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p(None)
+        _check(self._lib, self._lib.pedoni_shard_create(model._h, C.c_int32(rank), C.c_int32(world), idbuf, b,
+                                                        C.c_uint32(halo_cap), C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.pedoni_shard_destroy.restype = None
+            self._lib.pedoni_shard_destroy(self._h)
+            self._h = None
+
+    def begin(self) -> None:
+        _check(self._lib, self._lib.pedoni_shard_begin(self._h))
+
+    def tick_n(self, steps: int) -> None:
+        _check(self._lib, self._lib.pedoni_shard_tick_n(self._h, C.c_uint32(steps)))
+
+    def selftest(self) -> None:
+        _check(self._lib, self._lib.pedoni_shard_selftest(self._h))
+
+    def set_rebalance(self, every_ticks: int, max_rows_per_step: int = 4) -> None:
+        _check(self._lib, self._lib.pedoni_shard_set_rebalance(self._h, C.c_uint32(every_ticks),
+                                                               C.c_uint32(max_rows_per_step)))
+
+    def owned_count(self) -> int:
+        c = C.c_int32(0)
+        _check(self._lib, self._lib.pedoni_shard_owned_count(self._h, C.byref(c)))
+        return int(c.value)
+
+    def band(self):
+        a, b = C.c_int32(0), C.c_int32(0)
+        _check(self._lib, self._lib.pedoni_shard_band(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def download_owned(self):
+        """Owned agents (rows of the band) of the current sorted order, ghosts stripped."""
+        lo, hi = self.band()
+        pos, dest, vel, v0 = self.model.download()
+        with np.errstate(invalid="ignore"):
+            rows = np.trunc(np.nan_to_num(pos[:, 1] / np.float32(self.model.options.neighbor_grid_unit),
+                                          nan=-1e9)).astype(np.int64)
+            keep = (rows >= lo) & (rows < hi) & ~np.isnan(pos).any(axis=1)
+        return pos[keep], dest[keep], vel[keep], v0[keep]
+
+
+def local_group_tick_n(shards: Sequence[Shard], steps: int) -> None:
+    lib = shards[0]._lib
+    arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+    _check(lib, lib.pedoni_shard_local_group_tick_n(arr, C.c_uint32(len(shards)), C.c_uint32(steps)))

@@ -40,7 +40,9 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
     deps = srcs + list(CSRC.glob("*.hpp")) + [INCLUDE / "pedoni_hip.h"]
     if not force and _newer(out, deps):
         return out
-    cmd = [hipcc(), *HIP_FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-o", str(out), *map(str, srcs)]
+    # (librccl is NOT linked: shard.hpp resolves it with dlopen at first use)
+    cmd = [hipcc(), *HIP_FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-I/opt/rocm/include", "-o", str(out),
+           *map(str, srcs), "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

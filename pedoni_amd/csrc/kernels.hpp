@@ -1028,7 +1028,8 @@ halo_pack_kernel(const float2* __restrict__ pos, const float2* __restrict__ vel,
 // stable cell sort this reproduces the single-GPU order (lower bands hold lower indices).
 __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
                                    const uint32_t* __restrict__ from_above, uint32_t cap_each,
-                                   uint32_t base, uint32_t gap_end, float2* __restrict__ pos,
+                                   uint32_t n_behind, uint32_t base, uint32_t gap_end,
+                                   float2* __restrict__ pos,
                                    float2* __restrict__ vel, float* __restrict__ v0,
                                    uint32_t* __restrict__ dest, HaloIn* __restrict__ halo,
                                    FieldView field, GridView grid, int32_t band_lo, int32_t band_hi,
@@ -1037,11 +1038,13 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
                                    uint32_t* __restrict__ row_count)
 {
     // thread t < cap: landing slot base - cap + t (the list is right-aligned against base);
-    // thread t >= cap: slot gap_end + (t - cap).  Every slot gets a key -- the record's cell
-    // (same arithmetic as key_kernel) or DEAD for an unused slot -- so the pass that follows
-    // needs no K_KEY launch for the exchanged agents.
+    // thread t >= cap: slot gap_end + (t - cap), for the n_behind slots by which the host's
+    // bound of the arrays grows this tick (the list from above fills the first of them).
+    // Every slot gets a key -- the record's cell (same arithmetic as key_kernel) or DEAD for
+    // an unused slot -- so the pass that follows needs no K_KEY launch for the exchanged
+    // agents and never meets a stale key.
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2u * cap_each) return;
+    if (t >= cap_each + n_behind) return;
     uint32_t n_below = from_below ? min(from_below[0], cap_each) : 0u;
     uint32_t n_above = from_above ? min(from_above[0], cap_each) : 0u;
     if (t == 0) {

@@ -1285,8 +1285,9 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
     // The received lists land outside the own agents ([base - n, base) and behind everything
     // stored), and after the sort every live agent -- own, from below, from above -- sits in
     // [base, live): the host's bound of the end of the arrays must grow by the capacity of
-    // EVERY list received (the slots behind the stored agents are keyed even with no band
-    // above), although the true count (on the device) barely changes.  Re-read the count every
+    // EVERY list received (at least one: the slots behind the stored agents are keyed even
+    // with no band above; all `grow` of them get a key, DEAD beyond the list from above),
+    // although the true count (on the device) barely changes.  Re-read the count every
     // 8 ticks -- one stream sync per 8 ticks -- so launches never cover more than ~7 % idle
     // threads; and always before the arrays would have to grow.
     const uint32_t grow = cap_each * std::max(1u, (from_below_dev ? 1u : 0u) + (from_above_dev ? 1u : 0u));
@@ -1303,8 +1304,8 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
     const uint32_t* above = (const uint32_t*)from_above_dev;
     Timed t(m, PEDONI_K_HALO_UNPACK);
     if (t.rc) return t.rc;
-    hipLaunchKernelGGL(halo_unpack_kernel, dim3(blocks_for(2 * cap_each, 256)), dim3(256), 0,
-                       m->stream, below, above, cap_each, m->base, m->n_upper, m->d_pos[m->pv],
+    hipLaunchKernelGGL(halo_unpack_kernel, dim3(blocks_for(cap_each + grow, 256)), dim3(256), 0,
+                       m->stream, below, above, cap_each, grow, m->base, m->n_upper, m->d_pos[m->pv],
                        m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_halo, m->field, m->grid,
                        m->band_lo, m->band_hi, m->tick_parity & 1u, m->d_flags, m->d_key, m->d_scan_in,
                        m->d_row_count);
@@ -1552,3 +1553,6 @@ extern "C" int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mod
     hipFree(da); hipFree(db); hipFree(dout);
     return rc;
 }
+
+// ---- multi-GPU driver (pedoni_shard_*) ---------------------------------------------------------
+#include "shard.hpp"

@@ -1,0 +1,619 @@
+// shard.hpp -- the multi-GPU driver below the C-ABI (include/pedoni_hip.h, pedoni_shard_*).
+// Included at the end of pedoni_hip.hip: it works on PedoniModel's internals (stream, SoA
+// buffers, band) through the same functions the single-GPU entry points use.
+//
+// No reference counterpart (the reference is single-process).  One band
+// of neighbor-grid rows per rank.  Per tick, on the model's stream, with no host sync:
+//     exchange  ncclGroupStart { ncclSend / ncclRecv with rank-1 and rank+1 } ncclGroupEnd
+//               (the band's DOWN list to the band below, its UP list to the band above;
+//               fixed-capacity lists, ~0.1 MB: latency-bound, 2 of the 7 xGMI links)
+//     halo_unpack -> sort/despawn -> update_states -> halo_pack      (pedoni_hip_halo_tick)
+// Every `rebalance_every` ticks the bands are re-cut from the global per-row agent counts
+// (ncclAllReduce of a rows-long histogram): the rows that change owner travel to the
+// neighbour with their full state in one more grouped send / receive, right after a
+// sort/despawn pass, and are re-sorted there -- rows move whole, lower bands keep the lower
+// global indices, so the result stays bit-identical to one GPU.
+//
+// librccl is resolved with dlopen at first use: the library loads (and every single-GPU entry
+// point works) where RCCL is absent, and inside a PyTorch process the already loaded
+// librccl.so.1 is shared.
+#pragma once
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+RcclApi& rccl()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) {
+        api.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+        return api;
+    }
+    auto sym = [&](const char* n) -> void* {
+        void* p = dlsym(api.handle, n);
+        if (!p && api.error.empty()) api.error = std::string("librccl lacks ") + n;
+        return p;
+    };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    return api;
+}
+
+#define NCCL_TRY(expr)                                                                       \
+    do {                                                                                     \
+        ncclResult_t r_ = (expr);                                                            \
+        if (r_ != ncclSuccess)                                                               \
+            return fail(PEDONI_E_HIP, std::string(#expr) + ": " +                            \
+                                          (rccl().GetErrorString ? rccl().GetErrorString(r_) : "rccl error")); \
+    } while (0)
+
+// ---- device side of the re-cut ---------------------------------------------------------------
+// agents per OWNED grid row (zero elsewhere), read off cell_start
+__global__ void row_hist_kernel(const uint32_t* __restrict__ cs, int32_t cols, int32_t lo, int32_t hi,
+                                int32_t n_rows, uint32_t* __restrict__ hist)
+{
+    int32_t r = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n_rows) return;
+    hist[r] = (r >= lo && r < hi) ? cs[(int64_t)(r + 1) * cols] - cs[(int64_t)r * cols] : 0u;
+}
+
+// whole rows [row_a, row_b) of the sorted order -- one contiguous index range -- as a record
+// list (same record as the halo lists); header {count, overflow flag, 0, 0}
+__global__ void bulk_pack_kernel(const float2* __restrict__ pos, const float2* __restrict__ vel,
+                                 const float* __restrict__ v0, const uint32_t* __restrict__ dest,
+                                 const uint32_t* __restrict__ cs, int32_t cols, int32_t row_a, int32_t row_b,
+                                 uint32_t cap, uint32_t* __restrict__ out)
+{
+    const uint32_t begin = row_b > row_a ? cs[(int64_t)row_a * cols] : 0u;
+    const uint32_t end = row_b > row_a ? cs[(int64_t)row_b * cols] : 0u;
+    const uint32_t n = end - begin;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        out[0] = min(n, cap);
+        out[1] = n > cap ? 1u : 0u;
+        out[2] = out[3] = 0u;
+    }
+    if (t >= n || t >= cap) return;
+    const uint32_t i = begin + t;
+    uint32_t* r = out + PEDONI_HALO_HEADER_WORDS + (size_t)t * PEDONI_HALO_RECORD_WORDS;
+    const float2 p = pos[i], v = vel[i];
+    r[0] = __float_as_uint(p.x); r[1] = __float_as_uint(p.y);
+    r[2] = __float_as_uint(v.x); r[3] = __float_as_uint(v.y);
+    r[4] = __float_as_uint(v0[i]); r[5] = dest[i];
+}
+
+// appends both incoming lists behind everything stored: [at0, at0 + nA) then [.., + nB)
+__global__ void bulk_unpack_kernel(const uint32_t* __restrict__ in_a, const uint32_t* __restrict__ in_b,
+                                   uint32_t cap, uint32_t at0, float2* __restrict__ pos,
+                                   float2* __restrict__ vel, float* __restrict__ v0,
+                                   uint32_t* __restrict__ dest, HaloIn* __restrict__ halo)
+{
+    const uint32_t n_a = min(in_a[0], cap), n_b = min(in_b[0], cap);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        halo->n_above = n_a + n_b;          // the appended range, counted on the device
+        halo->counted = 1;
+        if (in_a[1] | in_b[1]) atomicOr(&halo->error, 1u);
+    }
+    const uint32_t* src;
+    uint32_t at;
+    if (t < cap) {
+        if (t >= n_a) return;
+        src = in_a + PEDONI_HALO_HEADER_WORDS + (size_t)t * PEDONI_HALO_RECORD_WORDS;
+        at = at0 + t;
+    } else {
+        const uint32_t k = t - cap;
+        if (k >= n_b) return;
+        src = in_b + PEDONI_HALO_HEADER_WORDS + (size_t)k * PEDONI_HALO_RECORD_WORDS;
+        at = at0 + n_a + k;
+    }
+    pos[at] = make_float2(__uint_as_float(src[0]), __uint_as_float(src[1]));
+    vel[at] = make_float2(__uint_as_float(src[2]), __uint_as_float(src[3]));
+    v0[at] = __uint_as_float(src[4]);
+    dest[at] = src[5];
+}
+
+} // namespace
+
+struct PedoniShard {
+    PedoniModel* m = nullptr;
+    int32_t rank = 0, world = 1;
+    std::vector<int32_t> bounds;      // world + 1 row boundaries, identical on every rank
+    uint32_t cap = 0, words_each = 0; // halo list capacity (agents) / words per list
+    uint32_t* d_send = nullptr;       // [down list][up list]
+    uint32_t* d_recv_below = nullptr; // laid out like the band below's buffer (its UP list is used)
+    uint32_t* d_recv_above = nullptr; // like the band above's buffer (its DOWN list is used)
+    ncclComm_t comm = nullptr;
+    bool begun = false;
+    // re-cut
+    uint32_t rebalance_every = 0, max_shift = 4, ticks = 0, recuts = 0;
+    uint32_t bulk_cap = 0, bulk_words = 0;
+    uint32_t* d_hist = nullptr;       // n_rows
+    uint32_t* h_hist = nullptr;       // pinned
+    uint32_t* d_bulk_send[2] = {nullptr, nullptr}; // [0] for the band below, [1] for the band above
+    uint32_t* d_bulk_recv[2] = {nullptr, nullptr}; // [0] from the band below, [1] from the band above
+    // members of a local group (one process, one device) reach each other directly
+    PedoniShard** group = nullptr;
+};
+
+namespace {
+
+int shard_check(PedoniShard* s)
+{
+    if (!s || !s->m) return fail(PEDONI_E_INVALID, "null shard");
+    return bind(s->m);
+}
+
+const uint32_t* shard_below(const PedoniShard* s) { return s->rank > 0 ? s->d_recv_below : nullptr; }
+const uint32_t* shard_above(const PedoniShard* s) { return s->rank + 1 < s->world ? s->d_recv_above : nullptr; }
+
+// the per-tick neighbour exchange of the packed lists, on the model's stream
+int shard_exchange_rccl(PedoniShard* s)
+{
+    if (s->world == 1) return PEDONI_OK;
+    if (!s->comm) return fail(PEDONI_E_INVALID, "shard has no communicator (created without an id)");
+    RcclApi& api = rccl();
+    hipStream_t st = s->m->stream;
+    const size_t n = s->words_each;
+    NCCL_TRY(api.GroupStart());
+    if (s->rank > 0) {
+        NCCL_TRY(api.Send(s->d_send, n, ncclUint32, s->rank - 1, s->comm, st));           // my DOWN list
+        NCCL_TRY(api.Recv(s->d_recv_below + n, n, ncclUint32, s->rank - 1, s->comm, st)); // its UP list
+    }
+    if (s->rank + 1 < s->world) {
+        NCCL_TRY(api.Send(s->d_send + n, n, ncclUint32, s->rank + 1, s->comm, st));       // my UP list
+        NCCL_TRY(api.Recv(s->d_recv_above, n, ncclUint32, s->rank + 1, s->comm, st));     // its DOWN list
+    }
+    NCCL_TRY(api.GroupEnd());
+    return PEDONI_OK;
+}
+
+int shard_exchange_local(PedoniShard* s)
+{
+    const size_t bytes = (size_t)s->words_each * sizeof(uint32_t);
+    if (s->rank > 0)
+        HIP_TRY(hipMemcpyAsync(s->d_recv_below + s->words_each, s->group[s->rank - 1]->d_send + s->words_each,
+                               bytes, hipMemcpyDeviceToDevice, s->m->stream));
+    if (s->rank + 1 < s->world)
+        HIP_TRY(hipMemcpyAsync(s->d_recv_above, s->group[s->rank + 1]->d_send, bytes, hipMemcpyDeviceToDevice,
+                               s->m->stream));
+    return PEDONI_OK;
+}
+
+int shard_pack(PedoniShard* s) { return halo_pack_from(s->m, s->d_send, s->cap, /*updated=*/false); }
+
+// ---- re-cut ------------------------------------------------------------------------------------
+// phase 1 (after a sort/despawn pass): this band's agents per owned row
+int recut_hist(PedoniShard* s)
+{
+    PedoniModel* m = s->m;
+    hipLaunchKernelGGL(row_hist_kernel, dim3(blocks_for((uint32_t)m->grid.rows, 256)), dim3(256), 0, m->stream,
+                       m->d_cs[m->cs], m->grid.cols, m->band_lo, m->band_hi, m->grid.rows, s->d_hist);
+    HIP_TRY(hipGetLastError());
+    return PEDONI_OK;
+}
+
+// the cut itself: same input, same result on every rank.  Boundaries move at most max_shift
+// rows per re-cut, never past a neighbour's rows that are not there to hand over, bands keep
+// >= 6 rows, and no transfer exceeds the bulk list capacity.
+void recut_bounds(const PedoniShard* s, const uint32_t* hist, std::vector<int32_t>& nb)
+{
+    const int32_t n_rows = s->m->grid.rows, world = s->world;
+    std::vector<int32_t> ideal((size_t)world + 1);
+    pedoni_shard_balanced_bounds(hist, (uint32_t)n_rows, world, 6, ideal.data());
+    nb = s->bounds;
+    const int32_t min_rows = 6;
+    for (int32_t b = 1; b < world; ++b) {
+        const int32_t old = s->bounds[b];
+        int32_t want = std::max(old - (int32_t)s->max_shift, std::min(old + (int32_t)s->max_shift, ideal[b]));
+        // stay inside the rows both neighbours held BEFORE the cut, keep every band >= min_rows
+        want = std::max(want, std::max(s->bounds[b - 1] + min_rows, nb[b - 1] + min_rows));
+        want = std::min(want, s->bounds[b + 1] - min_rows);
+        if (want < nb[b - 1] + min_rows) want = old;      // cannot satisfy both: leave it
+        // the rows handed over must fit one bulk list
+        auto moved = [&](int32_t to) {
+            uint64_t n = 0;
+            // donor sends rows [to-1, old-1) when the cut moves down, [old+1, to+1) when it moves up
+            const int32_t a = to < old ? to - 1 : old + 1, e = to < old ? old - 1 : to + 1;
+            for (int32_t r = std::max(a, 0); r < std::min(e, n_rows); ++r) n += hist[r];
+            return n;
+        };
+        while (want != old && moved(want) > s->bulk_cap) want += want < old ? 1 : -1;
+        nb[b] = want;
+    }
+}
+
+// phase 2: pack the rows this band hands over (old bounds), as decided by every rank alike
+int recut_pack(PedoniShard* s, const std::vector<int32_t>& nb)
+{
+    PedoniModel* m = s->m;
+    for (int dir = 0; dir < 2; ++dir) {
+        const int32_t b = s->rank + dir;                   // boundary index: lower (dir 0) / upper (dir 1)
+        int32_t row_a = 0, row_b = 0;
+        if (b >= 1 && b < s->world) {
+            const int32_t old = s->bounds[b], to = nb[b];
+            if (dir == 1 && to < old) { row_a = to - 1; row_b = old - 1; }      // my top rows go up
+            if (dir == 0 && to > old) { row_a = old + 1; row_b = to + 1; }      // my bottom rows go down
+        }
+        hipLaunchKernelGGL(bulk_pack_kernel, dim3(blocks_for(s->bulk_cap, 256)), dim3(256), 0, m->stream,
+                           m->d_pos[m->pv], m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_cs[m->cs],
+                           m->grid.cols, row_a, row_b, s->bulk_cap, s->d_bulk_send[dir]);
+    }
+    HIP_TRY(hipGetLastError());
+    return PEDONI_OK;
+}
+
+int recut_exchange_rccl(PedoniShard* s)
+{
+    RcclApi& api = rccl();
+    hipStream_t st = s->m->stream;
+    NCCL_TRY(api.GroupStart());
+    if (s->rank > 0) {
+        NCCL_TRY(api.Send(s->d_bulk_send[0], s->bulk_words, ncclUint32, s->rank - 1, s->comm, st));
+        NCCL_TRY(api.Recv(s->d_bulk_recv[0], s->bulk_words, ncclUint32, s->rank - 1, s->comm, st));
+    }
+    if (s->rank + 1 < s->world) {
+        NCCL_TRY(api.Send(s->d_bulk_send[1], s->bulk_words, ncclUint32, s->rank + 1, s->comm, st));
+        NCCL_TRY(api.Recv(s->d_bulk_recv[1], s->bulk_words, ncclUint32, s->rank + 1, s->comm, st));
+    }
+    NCCL_TRY(api.GroupEnd());
+    return PEDONI_OK;
+}
+
+int recut_exchange_local(PedoniShard* s)
+{
+    const size_t bytes = (size_t)s->bulk_words * sizeof(uint32_t);
+    if (s->rank > 0)
+        HIP_TRY(hipMemcpyAsync(s->d_bulk_recv[0], s->group[s->rank - 1]->d_bulk_send[1], bytes,
+                               hipMemcpyDeviceToDevice, s->m->stream));
+    if (s->rank + 1 < s->world)
+        HIP_TRY(hipMemcpyAsync(s->d_bulk_recv[1], s->group[s->rank + 1]->d_bulk_send[0], bytes,
+                               hipMemcpyDeviceToDevice, s->m->stream));
+    return PEDONI_OK;
+}
+
+// phase 3: take the incoming rows, adopt the new band, sort again (sfm.rs:58-77 semantics: a
+// second pass over unchanged positions drops nobody and only re-orders)
+int recut_apply(PedoniShard* s, const std::vector<int32_t>& nb)
+{
+    PedoniModel* m = s->m;
+    const bool moved = nb[s->rank] != s->bounds[s->rank] || nb[s->rank + 1] != s->bounds[s->rank + 1];
+    s->bounds = nb;
+    if (!moved) return PEDONI_OK;
+    // outer bands have no list from outside: an all-zero header stands in
+    if (s->rank == 0) HIP_TRY(hipMemsetAsync(s->d_bulk_recv[0], 0, 4 * sizeof(uint32_t), m->stream));
+    if (s->rank + 1 == s->world) HIP_TRY(hipMemsetAsync(s->d_bulk_recv[1], 0, 4 * sizeof(uint32_t), m->stream));
+    TRY(ensure_capacity(m, m->n_upper + 2 * s->bulk_cap));
+    hipLaunchKernelGGL(bulk_unpack_kernel, dim3(blocks_for(2 * s->bulk_cap, 256)), dim3(256), 0, m->stream,
+                       s->d_bulk_recv[0], s->d_bulk_recv[1], s->bulk_cap, m->n_upper, m->d_pos[m->pv],
+                       m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_halo);
+    HIP_TRY(hipGetLastError());
+    m->gap_end = m->n_upper;
+    m->n_upper += 2 * s->bulk_cap;
+    m->band_lo = nb[s->rank];
+    m->band_hi = nb[s->rank + 1];
+    m->keys_valid = false;          // every stored agent is keyed afresh against the new band
+    m->halo_keys_done = false;
+    m->sorted = false;
+    m->graph_valid = false;
+    TRY(sort_despawn(m));
+    s->recuts += 1;
+    return PEDONI_OK;
+}
+
+bool recut_due(const PedoniShard* s)
+{
+    return s->rebalance_every && s->world > 1 && (s->ticks % s->rebalance_every) == s->rebalance_every - 1;
+}
+
+// one tick of one rank over RCCL
+int shard_tick_rccl(PedoniShard* s)
+{
+    PedoniModel* m = s->m;
+    TRY(shard_exchange_rccl(s));
+    if (!recut_due(s)) {
+        TRY(pedoni_hip_halo_tick(m, shard_below(s), shard_above(s), s->d_send, s->cap));
+    } else {
+        TRY(pedoni_hip_halo_unpack(m, shard_below(s), shard_above(s), s->cap));
+        TRY(sort_despawn(m));
+        TRY(recut_hist(s));
+        NCCL_TRY(rccl().AllReduce(s->d_hist, s->d_hist, (size_t)m->grid.rows, ncclUint32, ncclSum, s->comm, m->stream));
+        HIP_TRY(hipMemcpyAsync(s->h_hist, s->d_hist, (size_t)m->grid.rows * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));          // stop the world: once per re-cut
+        std::vector<int32_t> nb;
+        recut_bounds(s, s->h_hist, nb);
+        TRY(recut_pack(s, nb));
+        TRY(recut_exchange_rccl(s));
+        TRY(recut_apply(s, nb));
+        TRY(update_states(m));
+        TRY(shard_pack(s));
+    }
+    s->ticks += 1;
+    return PEDONI_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pedoni_shard_unique_id(uint8_t id[PEDONI_SHARD_ID_BYTES])
+{
+    if (!id) return fail(PEDONI_E_INVALID, "null id");
+    RcclApi& api = rccl();
+    if (!api.handle || !api.error.empty()) return fail(PEDONI_E_HIP, api.error);
+    static_assert(sizeof(ncclUniqueId) == PEDONI_SHARD_ID_BYTES, "RCCL id size");
+    ncclUniqueId u;
+    NCCL_TRY(api.GetUniqueId(&u));
+    std::memcpy(id, &u, sizeof u);
+    return PEDONI_OK;
+}
+
+int pedoni_shard_balanced_bounds(const uint32_t* row_counts, uint32_t n_rows, int32_t world, int32_t min_rows,
+                                 int32_t* bounds_out)
+{
+    if (!row_counts || !bounds_out || world < 1 || min_rows < 1 || (uint64_t)world * (uint64_t)min_rows > n_rows)
+        return fail(PEDONI_E_INVALID, "balanced_bounds: bad arguments (need world * min_rows <= n_rows)");
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < n_rows; ++r) total += row_counts[r];
+    bounds_out[0] = 0;
+    bounds_out[world] = (int32_t)n_rows;
+    uint64_t run = 0;
+    uint32_t r = 0;
+    for (int32_t b = 1; b < world; ++b) {
+        // first row boundary at which the agents below reach b / world of the crowd
+        const uint64_t target = (total * (uint64_t)b + (uint64_t)world / 2) / (uint64_t)world;
+        while (r < n_rows && run + row_counts[r] <= target) run += row_counts[r++];
+        int32_t cut = (int32_t)r;
+        cut = std::max(cut, bounds_out[b - 1] + min_rows);
+        cut = std::min(cut, (int32_t)n_rows - (world - b) * min_rows);
+        bounds_out[b] = cut;
+        while ((int32_t)r < cut) run += row_counts[r++];   // keep the running sum at the cut
+    }
+    return PEDONI_OK;
+}
+
+int pedoni_shard_create(PedoniModel* m, int32_t rank, int32_t world, const uint8_t* id, const int32_t* row_bounds,
+                        uint32_t halo_cap, PedoniShard** out)
+{
+    TRY(bind(m));
+    if (!out || !row_bounds || world < 1 || rank < 0 || rank >= world || halo_cap == 0)
+        return fail(PEDONI_E_INVALID, "shard_create: bad arguments");
+    for (int32_t r = 0; r < world; ++r)
+        if (row_bounds[r + 1] - row_bounds[r] < 2 || row_bounds[0] != 0 || row_bounds[world] != m->grid.rows)
+            return fail(PEDONI_E_INVALID, "shard_create: row_bounds must rise from 0 to the grid's rows, >= 2 rows per band");
+    PedoniShard* s = new PedoniShard();
+    s->m = m;
+    s->rank = rank;
+    s->world = world;
+    s->bounds.assign(row_bounds, row_bounds + world + 1);
+    s->cap = halo_cap;
+    s->words_each = PEDONI_HALO_HEADER_WORDS + halo_cap * PEDONI_HALO_RECORD_WORDS;
+    auto bail = [&](int rc) { pedoni_shard_destroy(s); return rc; };
+    int rc = pedoni_hip_set_band(m, row_bounds[rank], row_bounds[rank + 1], halo_cap);
+    if (rc) return bail(rc);
+    const size_t words = 2 * (size_t)s->words_each;
+    for (uint32_t** p : {&s->d_send, &s->d_recv_below, &s->d_recv_above}) {
+        if ((rc = dev_alloc(p, words)) != PEDONI_OK) return bail(rc);
+        if (hipMemset(*p, 0, words * sizeof(uint32_t)) != hipSuccess) return bail(fail(PEDONI_E_HIP, "hipMemset failed"));
+    }
+    if (id) {
+        RcclApi& api = rccl();
+        if (!api.handle || !api.error.empty()) return bail(fail(PEDONI_E_HIP, api.error));
+        ncclUniqueId u;
+        std::memcpy(&u, id, sizeof u);
+        ncclResult_t r = api.CommInitRank(&s->comm, world, u, rank);
+        if (r != ncclSuccess) {
+            s->comm = nullptr;
+            return bail(fail(PEDONI_E_HIP, std::string("ncclCommInitRank: ") + api.GetErrorString(r)));
+        }
+    }
+    *out = s;
+    return PEDONI_OK;
+}
+
+void pedoni_shard_destroy(PedoniShard* s)
+{
+    if (!s) return;
+    if (s->m) {
+        hipSetDevice(s->m->device);
+        if (s->m->stream) hipStreamSynchronize(s->m->stream);
+    }
+    if (s->comm && rccl().CommDestroy) rccl().CommDestroy(s->comm);
+    hipFree(s->d_send); hipFree(s->d_recv_below); hipFree(s->d_recv_above); hipFree(s->d_hist);
+    for (int k = 0; k < 2; ++k) { hipFree(s->d_bulk_send[k]); hipFree(s->d_bulk_recv[k]); }
+    if (s->h_hist) hipHostFree(s->h_hist);
+    delete s;
+}
+
+int pedoni_shard_begin(PedoniShard* s)
+{
+    TRY(shard_check(s));
+    TRY(sort_despawn(s->m));
+    TRY(shard_pack(s));
+    s->begun = true;
+    return PEDONI_OK;
+}
+
+int pedoni_shard_tick_n(PedoniShard* s, uint32_t steps)
+{
+    TRY(shard_check(s));
+    if (!s->begun) return fail(PEDONI_E_INVALID, "shard_tick_n: call pedoni_shard_begin after loading the band");
+    if (s->group) return fail(PEDONI_E_INVALID, "shard_tick_n: a member of a local group ticks with pedoni_shard_local_group_tick_n");
+    for (uint32_t k = 0; k < steps; ++k) TRY(shard_tick_rccl(s));
+    return PEDONI_OK;
+}
+
+int pedoni_shard_owned_count(PedoniShard* s, int32_t* count)
+{
+    TRY(shard_check(s));
+    return pedoni_hip_owned_count(s->m, count);
+}
+
+int pedoni_shard_band(PedoniShard* s, int32_t* row_begin, int32_t* row_end)
+{
+    if (!s) return fail(PEDONI_E_INVALID, "null shard");
+    if (row_begin) *row_begin = s->bounds[s->rank];
+    if (row_end) *row_end = s->bounds[s->rank + 1];
+    return PEDONI_OK;
+}
+
+int pedoni_shard_set_rebalance(PedoniShard* s, uint32_t every_ticks, uint32_t max_rows_per_step)
+{
+    TRY(shard_check(s));
+    PedoniModel* m = s->m;
+    if (every_ticks && (max_rows_per_step == 0 || max_rows_per_step > 64))
+        return fail(PEDONI_E_INVALID, "set_rebalance: max_rows_per_step must be 1 .. 64");
+    s->rebalance_every = every_ticks;
+    if (!every_ticks) return PEDONI_OK;
+    s->max_shift = max_rows_per_step;
+    if (!s->d_hist) {
+        TRY(dev_alloc(&s->d_hist, (size_t)m->grid.rows));
+        HIP_TRY(hipHostMalloc((void**)&s->h_hist, (size_t)m->grid.rows * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    // one bulk list holds max_shift rows at 1.5x the halo capacity's row estimate (a halo list
+    // is sized for about two rows); the cut is limited to what fits, so this is never exceeded
+    const uint32_t bulk_cap = std::max(s->cap, s->cap * s->max_shift);
+    if (bulk_cap != s->bulk_cap) {
+        for (int k = 0; k < 2; ++k) {
+            hipFree(s->d_bulk_send[k]); hipFree(s->d_bulk_recv[k]);
+            s->d_bulk_send[k] = s->d_bulk_recv[k] = nullptr;
+        }
+        s->bulk_cap = bulk_cap;
+        s->bulk_words = PEDONI_HALO_HEADER_WORDS + bulk_cap * PEDONI_HALO_RECORD_WORDS;
+        for (int k = 0; k < 2; ++k) {
+            TRY(dev_alloc(&s->d_bulk_send[k], (size_t)s->bulk_words));
+            TRY(dev_alloc(&s->d_bulk_recv[k], (size_t)s->bulk_words));
+            HIP_TRY(hipMemset(s->d_bulk_recv[k], 0, (size_t)s->bulk_words * sizeof(uint32_t)));
+        }
+    }
+    return PEDONI_OK;
+}
+
+int pedoni_shard_selftest(PedoniShard* s)
+{
+    TRY(shard_check(s));
+    if (!s->comm) return s->world == 1 ? PEDONI_OK : fail(PEDONI_E_INVALID, "shard_selftest: no communicator");
+    if (s->world == 1) {
+        // a lone rank still proves the dlopen'ed ncclSend / ncclRecv work: one token to itself
+        RcclApi& api = rccl();
+        const uint32_t token = 0x5E1F0001u;
+        uint32_t got = 0;
+        HIP_TRY(hipMemcpyAsync(s->d_send, &token, sizeof token, hipMemcpyHostToDevice, s->m->stream));
+        NCCL_TRY(api.GroupStart());
+        NCCL_TRY(api.Send(s->d_send, 1, ncclUint32, 0, s->comm, s->m->stream));
+        NCCL_TRY(api.Recv(s->d_recv_above, 1, ncclUint32, 0, s->comm, s->m->stream));
+        NCCL_TRY(api.GroupEnd());
+        HIP_TRY(hipMemcpyAsync(&got, s->d_recv_above, sizeof got, hipMemcpyDeviceToHost, s->m->stream));
+        HIP_TRY(hipStreamSynchronize(s->m->stream));
+        HIP_TRY(hipMemsetAsync(s->d_send, 0, sizeof token, s->m->stream));
+        HIP_TRY(hipMemsetAsync(s->d_recv_above, 0, sizeof token, s->m->stream));
+        HIP_TRY(hipStreamSynchronize(s->m->stream));
+        return got == token ? PEDONI_OK : fail(PEDONI_E_HIP, "shard_selftest: the self-addressed token did not arrive");
+    }
+    // tokens travel through the very buffers / calls of the per-tick exchange; the lists are
+    // re-packed by pedoni_shard_begin afterwards
+    PedoniModel* m = s->m;
+    const uint32_t n = s->words_each;
+    std::vector<uint32_t> tok(2 * (size_t)n, 0u);
+    tok[0] = 0xD0000000u | (uint32_t)s->rank;              // first word of my DOWN list
+    tok[n] = 0xA0000000u | (uint32_t)s->rank;              // first word of my UP list
+    HIP_TRY(hipMemcpyAsync(s->d_send, tok.data(), tok.size() * sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
+    TRY(shard_exchange_rccl(s));
+    uint32_t got_below = 0, got_above = 0;
+    if (s->rank > 0)
+        HIP_TRY(hipMemcpyAsync(&got_below, s->d_recv_below + n, sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
+    if (s->rank + 1 < s->world)
+        HIP_TRY(hipMemcpyAsync(&got_above, s->d_recv_above, sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemsetAsync(s->d_send, 0, tok.size() * sizeof(uint32_t), m->stream));
+    HIP_TRY(hipMemsetAsync(s->d_recv_below, 0, tok.size() * sizeof(uint32_t), m->stream));
+    HIP_TRY(hipMemsetAsync(s->d_recv_above, 0, tok.size() * sizeof(uint32_t), m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (s->rank > 0 && got_below != (0xA0000000u | (uint32_t)(s->rank - 1)))
+        return fail(PEDONI_E_HIP, "shard_selftest: wrong token from the band below");
+    if (s->rank + 1 < s->world && got_above != (0xD0000000u | (uint32_t)(s->rank + 1)))
+        return fail(PEDONI_E_HIP, "shard_selftest: wrong token from the band above");
+    return PEDONI_OK;
+}
+
+int pedoni_shard_local_group_tick_n(PedoniShard** shards, uint32_t n_shards, uint32_t steps)
+{
+    if (!shards || n_shards == 0) return fail(PEDONI_E_INVALID, "local group: no shards");
+    for (uint32_t r = 0; r < n_shards; ++r) {
+        PedoniShard* s = shards[r];
+        if (!s || s->rank != (int32_t)r || s->world != (int32_t)n_shards || s->comm || !s->begun ||
+            s->m->stream != shards[0]->m->stream || s->bounds != shards[0]->bounds ||
+            s->rebalance_every != shards[0]->rebalance_every || s->bulk_cap != shards[0]->bulk_cap)
+            return fail(PEDONI_E_INVALID, "local group: shards must be ranks 0..n-1 of one world, begun, without a "
+                                          "communicator, on ONE stream, with equal bounds and re-cut settings");
+        s->group = shards;
+    }
+    for (uint32_t k = 0; k < steps; ++k) {
+        for (uint32_t r = 0; r < n_shards; ++r) { TRY(shard_check(shards[r])); TRY(shard_exchange_local(shards[r])); }
+        if (!recut_due(shards[0])) {
+            for (uint32_t r = 0; r < n_shards; ++r) {
+                PedoniShard* s = shards[r];
+                TRY(pedoni_hip_halo_tick(s->m, shard_below(s), shard_above(s), s->d_send, s->cap));
+            }
+        } else {
+            const int32_t n_rows = shards[0]->m->grid.rows;
+            std::vector<uint32_t> hist((size_t)n_rows, 0u);
+            for (uint32_t r = 0; r < n_shards; ++r) {
+                PedoniShard* s = shards[r];
+                TRY(pedoni_hip_halo_unpack(s->m, shard_below(s), shard_above(s), s->cap));
+                TRY(sort_despawn(s->m));
+                TRY(recut_hist(s));
+                HIP_TRY(hipMemcpyAsync(s->h_hist, s->d_hist, (size_t)n_rows * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                       s->m->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(shards[0]->m->stream));
+            for (uint32_t r = 0; r < n_shards; ++r)        // what ncclAllReduce(sum) does across processes
+                for (int32_t i = 0; i < n_rows; ++i) hist[(size_t)i] += shards[r]->h_hist[i];
+            std::vector<int32_t> nb;
+            recut_bounds(shards[0], hist.data(), nb);
+            for (uint32_t r = 0; r < n_shards; ++r) TRY(recut_pack(shards[r], nb));
+            for (uint32_t r = 0; r < n_shards; ++r) TRY(recut_exchange_local(shards[r]));
+            for (uint32_t r = 0; r < n_shards; ++r) {
+                PedoniShard* s = shards[r];
+                TRY(recut_apply(s, nb));
+                TRY(update_states(s->m));
+                TRY(shard_pack(s));
+            }
+        }
+        for (uint32_t r = 0; r < n_shards; ++r) shards[r]->ticks += 1;
+    }
+    return PEDONI_OK;
+}
+
+} // extern "C"

@@ -2,8 +2,10 @@
 // phase-2 round of the force kernel (pair_force_from_difference on register operands).
 //   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I pedoni_amd/csrc -I include \
 //         tools/microbench/valu_issue.hip -o /tmp/valu_issue && /tmp/valu_issue
-// Cycles are s_memtime ticks (shader clock) of the slowest wave; "cyc/inst/SIMD" =
-// cycles x 1 / (waves_per_simd x instructions per wave).
+// Every wave records its SIMD (HW_ID / XCC_ID) and absolute s_memtime stamps; per SIMD the host
+// takes (last end - first start) / (instructions issued by all its waves) -- the SIMD's issue
+// rate whatever order the arbiter served its waves in (it favours the oldest, so per-wave
+// medians mislead) -- and prints the median over SIMDs.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -63,14 +65,40 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, in
         }
         a0 = acc.x + acc.y;
     }
+    else if constexpr (OP == 6) {   // 4 independent v_pk_fma_f32 (x2): 2 fp32 FMAs per lane each
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+        const f2 pb = {b, b}, pc = {c, c};
+        for (int i = 0; i < iters; ++i) {
+            p0 = __builtin_elementwise_fma(p0, pb, pc); p1 = __builtin_elementwise_fma(p1, pb, pc);
+            p2 = __builtin_elementwise_fma(p2, pb, pc); p3 = __builtin_elementwise_fma(p3, pb, pc);
+            p0 = __builtin_elementwise_fma(p0, pb, pc); p1 = __builtin_elementwise_fma(p1, pb, pc);
+            p2 = __builtin_elementwise_fma(p2, pb, pc); p3 = __builtin_elementwise_fma(p3, pb, pc);
+        }
+        a0 = p0.x + p0.y; a1 = p1.x + p1.y; a2 = p2.x + p2.y; a3 = p3.x + p3.y;
+    } else if constexpr (OP == 7) {   // 8 independent v_cndmask / integer adds mix: v_add_u32
+        unsigned u0 = lane, u1 = lane + 1, u2 = lane + 2, u3 = lane + 3, u4 = lane + 4, u5 = lane + 5, u6 = lane + 6, u7 = lane + 7;
+        for (int i = 0; i < iters; ++i) {
+            u0 += u1; u1 += u2; u2 += u3; u3 += u4; u4 += u5; u5 += u6; u6 += u7; u7 += u0;
+        }
+        a0 = (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7);
+    }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d2 + d3);
-    if (lane == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if (lane == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        unsigned long long* r = cyc + 3 * (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6));
+        r[0] = ((unsigned long long)(xcc & 0xf) << 32) | (hw & 0xfff0u);   // xcc, se, sh, cu, pipe, simd
+        r[1] = t0;
+        r[2] = t1;
+    }
 }
 
+#include <map>
 template <int OP> void run(const char* name, int insts_per_iter_x8, float* out, unsigned long long* cyc)
 {
-    for (int w : {1, 2, 3, 4, 6, 8}) {
+    for (int w : {1, 2, 3, 4, 5, 6, 8}) {
         int blocks = 256 * w;   // 256-thread blocks: one wave per SIMD each; w blocks per CU
         hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, ITERS);
         hipDeviceSynchronize();
@@ -80,13 +108,21 @@ template <int OP> void run(const char* name, int insts_per_iter_x8, float* out, 
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        std::vector<unsigned long long> h(blocks * 4);
+        std::vector<unsigned long long> h((size_t)blocks * 4 * 3);
         hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
-        std::sort(h.begin(), h.end());
-        double med = (double)h[h.size() / 2], mx = (double)h.back();
-        double units = (double)ITERS / 8.0 * insts_per_iter_x8;   // "instructions" (or rounds) per wave
-        printf("%-28s waves/SIMD %d: %.3f ms  median %.0f cyc  max %.0f  -> %.2f cyc per unit per SIMD (median), clock %.2f GHz\n",
-               name, w, ms, med, mx, med / (w * units), mx / (ms * 1e6));
+        struct S { unsigned long long t0 = ~0ull, t1 = 0; int waves = 0; };
+        std::map<unsigned long long, S> simd;
+        for (size_t i = 0; i < h.size(); i += 3) {
+            S& s = simd[h[i]];
+            s.t0 = std::min(s.t0, h[i + 1]); s.t1 = std::max(s.t1, h[i + 2]); s.waves += 1;
+        }
+        const double units = (double)ITERS / 8.0 * insts_per_iter_x8;   // instructions (or rounds) per wave
+        std::vector<double> rate, occ;
+        for (auto& kv : simd) { rate.push_back((double)(kv.second.t1 - kv.second.t0) / (kv.second.waves * units)); occ.push_back(kv.second.waves); }
+        std::sort(rate.begin(), rate.end()); std::sort(occ.begin(), occ.end());
+        printf("%-28s blocks/CU %d: %.3f ms, %zu SIMDs seen, waves/SIMD min %.0f median %.0f max %.0f -> cycles per unit per SIMD: "
+               "min %.2f median %.2f max %.2f\n", name, w, ms, simd.size(), occ.front(), occ[occ.size() / 2], occ.back(),
+               rate.front(), rate[rate.size() / 2], rate.back());
         hipEventDestroy(e0); hipEventDestroy(e1);
     }
 }
@@ -94,11 +130,13 @@ template <int OP> void run(const char* name, int insts_per_iter_x8, float* out, 
 int main()
 {
     float* out; hipMalloc(&out, 256 * 8 * 256 * 4);
-    unsigned long long* cyc; hipMalloc(&cyc, 256 * 8 * 4 * 8);
+    unsigned long long* cyc; hipMalloc(&cyc, 256 * 8 * 4 * 3 * 8);
     run<0>("v_fma_f32 x8 independent", 64, out, cyc);
     run<1>("v_fma_f32 dependent chain", 64, out, cyc);
     run<2>("v_sqrt_f32 x8 independent", 64, out, cyc);
     run<3>("v_fma_f64 x4 independent", 64, out, cyc);
+    run<6>("v_pk_fma_f32 x4 independent", 64, out, cyc);
+    run<7>("v_add_u32 x8 chain", 64, out, cyc);
     run<4>("exact pair force (round)", 1, out, cyc);
     run<5>("fast pair force (round)", 1, out, cyc);
     return 0;
