@@ -139,17 +139,53 @@ def cpu_baseline(size, field, obstacles, pos, dest, v0, vel, budget_s: float = 2
 
 
 def pmc_traffic(workload: str):
-    """HBM bytes per force-kernel launch from the committed rocprofv3 --pmc passes
-    (profiles/*pmc*.json written by tools/pmc_summary.py), or None."""
-    best = None
-    for p in sorted((ROOT / "profiles").glob("*pmc*.json")):
+    """HBM bytes per force-kernel launch from the newest committed rocprofv3 --pmc passes
+    (profiles/*pmc_force*.json written by tools/pmc_summary.py) for this workload, with the
+    profile it came from -- (bytes, tag) or (None, None)."""
+    best = (None, None)
+    for p in sorted((ROOT / "profiles").glob("*pmc_force*.json"), key=lambda q: q.stat().st_mtime):
         try:
             d = json.loads(p.read_text())
         except Exception:
             continue
         if d.get("workload") == workload and d.get("kernel", "").startswith("force"):
-            best = d.get("hbm_bytes_per_launch")
+            best = (d.get("hbm_bytes_per_launch"), p.name)
     return best
+
+
+# VALU issue on gfx950 (tools/microbench/valu_issue.hip, profiles/r02_valu_issue.txt): a SIMD-32
+# issues one wave64 VALU instruction per 2 cycles at best (MI355X_MICROARCH.md); with the 6
+# waves per SIMD the force kernel runs at, independent v_fma_f32 streams measured 2.3-2.4.
+VALU_CYCLES_PER_INST = 2.0
+N_SIMDS = 1024
+
+
+def valu_floor(avg_launch_ms: float):
+    """Instruction-issue floor of the force kernel from the newest committed stall-counter
+    profile (profiles/*_stalls.json, tools/profile_stalls.sh): SQ_INSTS_VALU wave-instructions
+    per launch x 2 cycles / 1024 SIMDs, priced at the clock the profiled launches held
+    (GRBM_GUI_ACTIVE / 8 XCDs per launch / its SQ_BUSY time is not available, so the clock is
+    cycles per launch / the profiled launch duration)."""
+    best = None
+    for p in sorted((ROOT / "profiles").glob("*_stalls.json"), key=lambda q: q.stat().st_mtime):
+        try:
+            d = json.loads(p.read_text())
+        except Exception:
+            continue
+        for k, v in d.items():
+            if "force_kernel_queue<0" in k and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
+                best = (v, p.name)
+    if not best:
+        return None
+    v, tag = best
+    insts = v["SQ_INSTS_VALU"]
+    floor_cycles = insts * VALU_CYCLES_PER_INST / N_SIMDS
+    launch_cycles = v["GRBM_GUI_ACTIVE"] / 8.0           # rocprofv3 sums the 8 XCDs
+    clock_ghz = v.get("clock_ghz") or 2.1
+    floor_ms = floor_cycles / (clock_ghz * 1e6)
+    return {"insts_per_launch": insts, "cycles_per_inst": VALU_CYCLES_PER_INST, "simds": N_SIMDS,
+            "floor_ms": floor_ms, "frac": floor_ms / avg_launch_ms,
+            "frac_in_profiled_run": floor_cycles / launch_cycles, "clock_ghz": clock_ghz, "profile": tag}
 
 
 def main() -> None:
@@ -167,6 +203,8 @@ def main() -> None:
                     help="c3 only: agents per m^2 (SURVEY 8(d) sweeps 0.25 / 1 / 4; the metric is quoted at 1)")
     ap.add_argument("--work-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-leg", action="store_true",
+                    help="skip the secondary PEDONI_MATH_FAST measurement of the same crowd")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-profile", action="store_true",
                     help="skip the per-kernel hipEvent pairs in the timed region")
@@ -238,16 +276,51 @@ def main() -> None:
     model = abi.HipModel(opt, (width, height), field.distance_map, field.potential_maps,
                          field.unit, obstacles, device=local_rank)
 
+    exchange = None
     if G > 1 or force_sharded:
-        from pedoni_amd.sharded import ShardedModel
+        from pedoni_amd.sharded import ShardedModel, band_rows, default_halo_cap
         model.set_stream(stream.cuda_stream)
-        runner = ShardedModel(model, rank, G, dist, torch,
-                              expected_row_agents=int(width * 1.4 * density),
-                              overlap=os.environ.get("PEDONI_OVERLAP") == "1")
+        rows, _ = model.neighbor_grid_shape()
+        bounds = band_rows(rows, G)                # uniform crowd: equal rows = equal agents
+        cap = default_halo_cap(int(width * 1.4 * density))
+        runner = shard = None
+        if os.environ.get("PEDONI_EXCHANGE", "rccl") == "rccl" and dist.get_backend() == "nccl":
+            # the driver below the C-ABI: libpedoni_hip owns an RCCL communicator and sends /
+            # receives the lists itself (ncclSend / ncclRecv with rank +- 1 on the model's
+            # stream).  torch.distributed only carries the 128-byte id and the timing barrier.
+            ok, why = 1, ""
+            try:
+                idt = torch.zeros(abi.SHARD_ID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(abi.shard_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                shard = abi.Shard(model, rank, G, bounds, cap, unique_id=bytes(idt.cpu().numpy().tobytes()))
+                shard.selftest()                   # a token ring through the very send / recv pair
+            except Exception as e:                 # noqa: BLE001 -- reported, then the fallback runs
+                ok, why = 0, str(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                exchange = "direct RCCL ncclSend/ncclRecv to rank+-1, driven by libpedoni_hip (pedoni_shard_tick_n)"
+            else:
+                print(f"[bench] rank {rank}: direct RCCL path unavailable ({why or 'another rank failed'}); "
+                      "falling back to torch.distributed all_gather", file=sys.stderr)
+                if shard is not None:
+                    shard.close()
+                shard = None
+                model.close()
+                model = abi.HipModel(opt, (width, height), field.distance_map, field.potential_maps,
+                                     field.unit, obstacles, device=local_rank)
+                model.set_stream(stream.cuda_stream)
+        if shard is None:
+            runner = ShardedModel(model, rank, G, dist, torch, halo_cap=cap, bounds=bounds,
+                                  overlap=os.environ.get("PEDONI_OVERLAP") == "1")
+            exchange = "torch.distributed all_gather_into_tensor (RCCL), driven from Python"
+        lo, hi = bounds[rank], bounds[rank + 1]
         # this rank's agents: exactly its own band of grid rows (2 m clear of the outer walls)
-        y_lo, y_hi = runner.lo * 1.4 + 0.01, runner.hi * 1.4 - 0.01
+        y_lo, y_hi = lo * 1.4 + 0.01, hi * 1.4 - 0.01
     else:
-        runner = None
+        runner = shard = None
         y_lo, y_hi = 0.0, height
     if custom_crowd is not None:
         pos, dest, v0, vel = custom_crowd(field)
@@ -255,7 +328,11 @@ def main() -> None:
         pos, dest, v0, vel = uniform_crowd(
             n_per, (12.0, width - 12.0), (max(y_lo, 2.0), min(y_hi, height - 2.0)), seed=12345 + rank)
 
-    if runner is not None:
+    if shard is not None:
+        model.append(pos, dest, v0, vel)
+        shard.begin()
+        step_fn = shard.tick_n
+    elif runner is not None:
         assert (runner.owner_of(pos[:, 1]) == rank).all()
         runner.load(pos, dest, v0, vel)
         step_fn = runner.tick_n
@@ -270,12 +347,13 @@ def main() -> None:
 
     step_fn(args.warmup)
     barrier()
-    sharded = runner is not None
+    sharded = runner is not None or shard is not None
     n_before = model.owned_count() if sharded else model.get_pedestrian_count()
     if not args.no_profile:
-        # one hipEvent pair per step around the dominant kernel only (a pair around every
-        # kernel costs ~40 us/step; the full breakdown is taken after the timed region)
-        model.profile(True, kernels=[abi.K_FORCE])
+        # inside the timed region the dominant kernel is event-timed on every 8th tick only:
+        # timed ticks launch eagerly (+ one hipEvent pair), the others replay the captured tick
+        # pair; the full per-kernel breakdown is a separate pass after the timed region
+        model.profile(True, kernels=[abi.K_FORCE], every=8)
         model.kernel_times(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -315,7 +393,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "agents_total": int(round(agents_total)),
-                       "math_mode": args.math, "parallelism": f"row-bands x{G}" if sharded else "single GPU",
+                       "math_mode": args.math, "parallelism": f"row-bands x{G}; {exchange}" if sharded else "single GPU",
                        "field_build_s": round(t_field, 2),
                        "tick_algorithmic_GBps": BYTES_TICK * value / 1e9},
         }
@@ -323,15 +401,52 @@ def main() -> None:
         if fk and fk["launches"]:
             avg_ms = fk["total_ms"] / fk["launches"]
             achieved = BYTES_FORCE * agents_local / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_tag = pmc_traffic(workload)
+            valu = valu_floor(avg_ms) if args.math == "exact" and args.workload == "c3" and G == 1 else None
+            hbm_frac = achieved / HBM_PEAK_GBS
             out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(workload),
+                # the roof the kernel is closer to: HBM bytes at 8 TB/s, or VALU issue at one
+                # wave instruction per 2 cycles per SIMD (no MFMA on this path)
+                "bound": "valu" if valu and valu["frac"] > hbm_frac else "hbm",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": hbm_frac, "traffic": traffic, "traffic_profile": traffic_tag,
                 "kernel": "force_integrate", "avg_launch_ms": avg_ms,
+                "timed_launches": fk["launches"],
                 "algorithmic_bytes_per_launch": BYTES_FORCE * agents_local,
+                "valu": valu,
             }
             out["kernel_ms_per_step"] = breakdown  # separate pass, every kernel event-timed
         else:
             out["roofline"] = None
+        if G == 1 and args.math == "exact" and not args.no_fast_leg:
+            # the same crowd in PEDONI_MATH_FAST (hardware rcp / rsq / sqrt / exp with exact
+            # decisions): inside north_star's 1e-5 per step at these sizes
+            # (tests/test_gpu_fullsize.py::test_fast_math_*), reported beside the headline,
+            # which stays the bit-identical exact mode
+            fopt = abi.Options(math_mode=abi.MATH_FAST, gpu_work_size=args.work_size,
+                               initial_capacity=int(n_per * 1.3), use_distance_map=args.workload != "c4seg")
+            fm = abi.HipModel(fopt, (width, height), field.distance_map, field.potential_maps, field.unit,
+                              obstacles, device=local_rank)
+            fm.append(pos, dest, v0, vel)
+            fm.tick_n(args.warmup)
+            fm.synchronize()
+            nb = fm.get_pedestrian_count()
+            fm.profile(True, kernels=[abi.K_FORCE], every=8)
+            fm.kernel_times(reset=True)
+            t0 = time.perf_counter()
+            fm.tick_n(args.steps)
+            fm.synchronize()
+            el = time.perf_counter() - t0
+            fk2 = fm.kernel_times(reset=True).get("force_integrate", {})
+            fm.profile(False)
+            na = fm.get_pedestrian_count()
+            out["fast_math"] = {
+                "value": 0.5 * (nb + na) * args.steps / el, "unit": "agent-steps/s",
+                "ms_per_step": 1e3 * el / args.steps, "math_mode": "fast",
+                "force_avg_launch_ms": fk2["total_ms"] / fk2["launches"] if fk2.get("launches") else None,
+                "tolerance": "1e-5 relative per step from identical state (north_star); exact mode is bit-identical",
+            }
+            fm.close()
         if G == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((width, height), field, obstacles, pos, dest, v0, vel,
                                                args.cpu_budget, args.workload != "c4seg")

@@ -101,6 +101,18 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
                       uint32_t n_maps, uint32_t field_rows, uint32_t field_cols,
                       float field_unit, const PedoniObstacle* obstacles, uint32_t n_obstacles,
                       int device, PedoniModel** out);
+/* [ext] the same for one band of a sharded run: the map pointers still address the FULL
+ * field_rows x field_cols host arrays, but only the texel rows [map_row_begin, map_row_end) are
+ * copied to the device (a band of a 1000 x 8000 m field needs 1/8 of each 512 MB map).  The rows
+ * must cover every position the band's agents -- owned, ghost, or one tick's step beyond --
+ * can sample: pedoni_shard_map_rows computes them.  Sampling outside them is never a fault: it
+ * raises a sticky device status (PEDONI_E_CAPACITY from the next read of device state). */
+int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
+                           const float* distance_map, const float* const* potential_maps,
+                           uint32_t n_maps, uint32_t field_rows, uint32_t field_cols,
+                           float field_unit, const PedoniObstacle* obstacles, uint32_t n_obstacles,
+                           int device, uint32_t map_row_begin, uint32_t map_row_end,
+                           PedoniModel** out);
 void pedoni_hip_destroy(PedoniModel* m);
 
 /* [trait] PedestrianModel::spawn_pedestrians (models/mod.rs:18; sfm.rs:48-89): append
@@ -172,6 +184,9 @@ int pedoni_hip_synchronize(PedoniModel* m);
 /* bit k of `kernel_mask` = time launches of PEDONI_K_<k> with a hipEvent pair (-1 = all,
  * 0 = off).  An event pair costs a few microseconds per launch on the stream. */
 int pedoni_hip_profile(PedoniModel* m, int32_t kernel_mask);
+/* inside pedoni_hip_tick_n only every `every_ticks`-th tick is timed (default 1 = all): the
+ * timed ticks launch eagerly, the others may replay the captured graph */
+int pedoni_hip_profile_every(PedoniModel* m, uint32_t every_ticks);
 int pedoni_hip_kernel_times(PedoniModel* m, PedoniKernelTimes* out, int32_t reset);
 const char* pedoni_hip_kernel_name(int32_t k);
 
@@ -233,6 +248,11 @@ int pedoni_hip_owned_count(PedoniModel* m, int32_t* count);
 typedef struct PedoniShard PedoniShard;
 #define PEDONI_SHARD_ID_BYTES 128
 int pedoni_shard_unique_id(uint8_t id[PEDONI_SHARD_ID_BYTES]);
+/* texel rows of the field maps a band of grid rows [row_begin, row_end) needs, `slack_rows` grid
+ * rows of room on either side included (room for the periodic re-cut to move the band) */
+int pedoni_shard_map_rows(int32_t row_begin, int32_t row_end, int32_t slack_rows, float neighbor_grid_unit,
+                          float field_unit, uint32_t field_rows, uint32_t* map_row_begin,
+                          uint32_t* map_row_end);
 int pedoni_shard_balanced_bounds(const uint32_t* row_counts, uint32_t n_rows, int32_t world,
                                  int32_t min_rows, int32_t* bounds_out /* world + 1 */);
 /* `id` NULL: no communicator (world == 1, or a member of a local group, below).  The model
@@ -250,8 +270,12 @@ int pedoni_shard_band(PedoniShard* s, int32_t* row_begin, int32_t* row_end);
 int pedoni_shard_selftest(PedoniShard* s);
 /* every `every_ticks` ticks (0 = never) the bands are re-cut from the global per-row agent
  * counts so that each holds about N / world agents: the rows that change owner travel, full
- * state, to the neighbour in one grouped send / receive; results stay bit-identical to one GPU */
-int pedoni_shard_set_rebalance(PedoniShard* s, uint32_t every_ticks, uint32_t max_rows_per_step);
+ * state, to the neighbour in one grouped send / receive; results stay bit-identical to one GPU.
+ * `map_slack_rows` < 0: every rank holds the whole field maps; >= 0: every rank's model was
+ * created with pedoni_hip_create_rows over pedoni_shard_map_rows(its initial band, that slack),
+ * and no boundary moves further than the slack from where it started */
+int pedoni_shard_set_rebalance(PedoniShard* s, uint32_t every_ticks, uint32_t max_rows_per_step,
+                               int32_t map_slack_rows);
 /* G shards of ONE process on one device, the transport replaced by device copies: the same
  * driver code, testable on a single GPU (tests/test_gpu_shard.py).  Ticks all shards in
  * lockstep. */

@@ -39,7 +39,8 @@ SYMBOLS = [
     "pedoni_hip_halo_tick_begin", "pedoni_hip_halo_tick_end",
     "pedoni_hip_owned_count",
     "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_selftest_field", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
-    "pedoni_hip_debug_set_status",
+    "pedoni_hip_debug_set_status", "pedoni_hip_profile_every",
+    "pedoni_hip_create_rows", "pedoni_shard_map_rows",
     "pedoni_shard_unique_id", "pedoni_shard_balanced_bounds", "pedoni_shard_create", "pedoni_shard_destroy",
     "pedoni_shard_begin", "pedoni_shard_tick_n", "pedoni_shard_owned_count", "pedoni_shard_band",
     "pedoni_shard_selftest", "pedoni_shard_set_rebalance", "pedoni_shard_local_group_tick_n",
@@ -191,7 +192,10 @@ class HipModel:
 
     def __init__(self, options: Options, size: Sequence[float], distance_map: np.ndarray,
                  potential_maps: Sequence[np.ndarray], field_unit: float,
-                 obstacles: Optional[np.ndarray] = None, device: int = 0):
+                 obstacles: Optional[np.ndarray] = None, device: int = 0,
+                 map_rows: Optional[Sequence[int]] = None):
+        """`map_rows` = (begin, end): upload only these texel rows of every (full-size) map --
+        one band of a sharded run (pedoni_hip_create_rows; see shard_map_rows)."""
         self._lib = load_library()
         self._h = C.c_void_p(None)
         dm = _f32(distance_map)
@@ -206,11 +210,13 @@ class HipModel:
         self.options = options
         self.n_maps = len(pms)
         opt = options._c()
-        rc = self._lib.pedoni_hip_create(
+        r0, r1 = (0, dm.shape[0]) if map_rows is None else (int(map_rows[0]), int(map_rows[1]))
+        self.map_rows = (r0, r1)
+        rc = self._lib.pedoni_hip_create_rows(
             C.byref(opt), C.c_float(size[0]), C.c_float(size[1]), _ptr(dm, C.c_float), ptrs,
             C.c_uint32(len(pms)), C.c_uint32(dm.shape[0]), C.c_uint32(dm.shape[1]),
             C.c_float(field_unit), obs.ctypes.data_as(C.POINTER(_Obstacle)),
-            C.c_uint32(obs.shape[0]), C.c_int(device), C.byref(self._h))
+            C.c_uint32(obs.shape[0]), C.c_int(device), C.c_uint32(r0), C.c_uint32(r1), C.byref(self._h))
         _check(self._lib, rc)
 
     # -- lifetime ----------------------------------------------------------------
@@ -347,12 +353,14 @@ class HipModel:
     def synchronize(self) -> None:
         _check(self._lib, self._lib.pedoni_hip_synchronize(self._h))
 
-    def profile(self, enable, kernels: Optional[Sequence[int]] = None) -> None:
+    def profile(self, enable, kernels: Optional[Sequence[int]] = None, every: int = 1) -> None:
         """Time kernel launches with hipEvent pairs: all kernels, or only the PEDONI_K_*
-        indices in `kernels` (each pair costs a few microseconds on the stream)."""
+        indices in `kernels` (each pair costs a few microseconds on the stream); inside tick_n
+        only every `every`-th tick is timed (the others may replay the captured graph)."""
         mask = 0
         if enable:
             mask = 0xFF if kernels is None else sum(1 << k for k in kernels)
+        _check(self._lib, self._lib.pedoni_hip_profile_every(self._h, C.c_uint32(max(1, every))))
         _check(self._lib, self._lib.pedoni_hip_profile(self._h, C.c_int32(mask)))
 
     def kernel_times(self, reset: bool = False) -> dict:
@@ -422,6 +430,17 @@ def shard_unique_id() -> bytes:
     return bytes(buf)
 
 
+def shard_map_rows(row_begin: int, row_end: int, slack_rows: int, neighbor_grid_unit: float, field_unit: float,
+                   field_rows: int):
+    """Texel rows [begin, end) of the field maps a band of grid rows needs (pure host code)."""
+    lib = load_library()
+    a, b = C.c_uint32(0), C.c_uint32(0)
+    _check(lib, lib.pedoni_shard_map_rows(C.c_int32(row_begin), C.c_int32(row_end), C.c_int32(slack_rows),
+                                          C.c_float(neighbor_grid_unit), C.c_float(field_unit),
+                                          C.c_uint32(field_rows), C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
+
+
 def balanced_bounds(row_counts, world: int, min_rows: int = 6) -> list:
     """Row boundaries that give every band about the same number of AGENTS (pure host code)."""
     lib = load_library()
@@ -465,9 +484,10 @@ class Shard:
     def selftest(self) -> None:
         _check(self._lib, self._lib.pedoni_shard_selftest(self._h))
 
-    def set_rebalance(self, every_ticks: int, max_rows_per_step: int = 4) -> None:
+    def set_rebalance(self, every_ticks: int, max_rows_per_step: int = 4, map_slack_rows: int = -1) -> None:
         _check(self._lib, self._lib.pedoni_shard_set_rebalance(self._h, C.c_uint32(every_ticks),
-                                                               C.c_uint32(max_rows_per_step)))
+                                                               C.c_uint32(max_rows_per_step),
+                                                               C.c_int32(map_slack_rows)))
 
     def owned_count(self) -> int:
         c = C.c_int32(0)

@@ -13,8 +13,12 @@ LIBDIR = ROOT / "pedoni_amd" / "lib"
 INCLUDE = ROOT / "include"
 
 # -ffp-contract=off: the reference (Rust) never fuses a*b+c; parity is bit-level.
+# -fno-slp-vectorize: the SLP vectoriser pairs x / y arithmetic into v_pk_*_f32; on gfx950 a packed
+# op costs about two plain ones (tools/microbench/valu_issue.hip: v_pk_fma_f32 4.4 cycles against
+# 2.6 for v_fma_f32 at 6 waves/SIMD) and the pairing adds register moves: the force kernel is 3 %
+# faster without it (tools/ab_flags.sh, round 2).  Same operations, same bits.
 HIP_FLAGS = [
-    "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
+    "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "--offload-arch=gfx950",
     "-shared", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-value",
 ]
 

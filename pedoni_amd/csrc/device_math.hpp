@@ -193,31 +193,54 @@ struct FieldView {
     // where the division does
     float inv_unit;
     int32_t unit_pow2;
+    // A band of a sharded run may hold only the texel rows [y_lo, y_hi) of every map (the map
+    // pointers are then biased by -y_lo rows, so indexing stays in full-field coordinates).
+    // Whole field: y_lo = 0, y_hi = rows.  A texel inside the field but outside the slice is
+    // never read: it returns the out-of-field value and raises `status` bit 2 (loudly wrong
+    // instead of a fault) -- the slice is sized so that no agent of the band gets there.
+    int32_t y_lo, y_hi;
+    uint32_t* status;
 };
 
-// util.rs:30-36 + :53-56: texel or 1e12 when the index is negative / out of shape
-__device__ __forceinline__ float texel(const float* g, int32_t rows, int32_t cols, int64_t x,
-                                       int64_t y)
+// shape of one map as the sampling functions see it
+struct MapDims {
+    int32_t rows, cols, y_lo, y_hi;
+    uint32_t* status;
+};
+__device__ __forceinline__ MapDims dims_of(const FieldView& f)
 {
-    if (x < 0 || y < 0 || y >= rows || x >= cols) return 1e12f;
-    return g[(size_t)y * (size_t)cols + (size_t)x];
+    MapDims d;
+    d.rows = f.rows; d.cols = f.cols; d.y_lo = f.y_lo; d.y_hi = f.y_hi; d.status = f.status;
+    return d;
+}
+constexpr uint32_t STATUS_FIELD_SLICE = 4u; // a texel outside the uploaded rows of the maps was asked for
+
+// util.rs:30-36 + :53-56: texel or 1e12 when the index is negative / out of shape
+__device__ __forceinline__ float texel(const float* g, const MapDims& m, int64_t x, int64_t y)
+{
+    if (x < 0 || y < 0 || y >= m.rows || x >= m.cols) return 1e12f;
+    if (y < m.y_lo || y >= m.y_hi) {                     // in the field, not in this band's slice
+        atomicOr(m.status, STATUS_FIELD_SLICE);
+        return 1e12f;
+    }
+    return g[(int64_t)y * (int64_t)m.cols + x];
 }
 
 // util.rs:44-58
-__device__ __forceinline__ float bilinear(const float* g, int32_t rows, int32_t cols, float px,
-                                          float py)
+__device__ __forceinline__ float bilinear(const float* g, const MapDims& m, float px, float py)
 {
+    const int32_t cols = m.cols;
     float bx = __builtin_floorf(px), by = __builtin_floorf(py);
     float tx = px - bx, ty = py - by;
     float sx = 1.0f - tx, sy = 1.0f - ty;
     int64_t ix = f32_as_i32(bx), iy = f32_as_i32(by);
     float g00, g01, g10, g11;
-    if (ix >= 0 && iy >= 0 && ix + 1 < cols && iy + 1 < rows) {   // all four texels in bounds
-        const float* r0 = g + (uint32_t)iy * (uint32_t)cols + (uint32_t)ix;
+    if (ix >= 0 && iy >= m.y_lo && ix + 1 < cols && iy + 1 < m.y_hi) {   // all four texels in bounds
+        const float* r0 = g + ((int64_t)iy * (int64_t)cols + ix);
         g00 = r0[0]; g01 = r0[1]; g10 = r0[cols]; g11 = r0[cols + 1];
     } else {
-        g00 = texel(g, rows, cols, ix, iy);     g01 = texel(g, rows, cols, ix + 1, iy);
-        g10 = texel(g, rows, cols, ix, iy + 1); g11 = texel(g, rows, cols, ix + 1, iy + 1);
+        g00 = texel(g, m, ix, iy);     g01 = texel(g, m, ix + 1, iy);
+        g10 = texel(g, m, ix, iy + 1); g11 = texel(g, m, ix + 1, iy + 1);
     }
     float y = 0.0f;
     y += sy * sx * g00;
@@ -228,16 +251,16 @@ __device__ __forceinline__ float bilinear(const float* g, int32_t rows, int32_t 
 }
 
 // util.rs:61-75 (first digit = row offset, second = column offset)
-__device__ __forceinline__ v2 sobel(const float* g, int32_t rows, int32_t cols, float px, float py)
+__device__ __forceinline__ v2 sobel(const float* g, const MapDims& m, float px, float py)
 {
-    float u00 = bilinear(g, rows, cols, px + -1.0f, py + -1.0f);
-    float u01 = bilinear(g, rows, cols, px + 0.0f, py + -1.0f);
-    float u02 = bilinear(g, rows, cols, px + 1.0f, py + -1.0f);
-    float u10 = bilinear(g, rows, cols, px + -1.0f, py + 0.0f);
-    float u12 = bilinear(g, rows, cols, px + 1.0f, py + 0.0f);
-    float u20 = bilinear(g, rows, cols, px + -1.0f, py + 1.0f);
-    float u21 = bilinear(g, rows, cols, px + 0.0f, py + 1.0f);
-    float u22 = bilinear(g, rows, cols, px + 1.0f, py + 1.0f);
+    float u00 = bilinear(g, m, px + -1.0f, py + -1.0f);
+    float u01 = bilinear(g, m, px + 0.0f, py + -1.0f);
+    float u02 = bilinear(g, m, px + 1.0f, py + -1.0f);
+    float u10 = bilinear(g, m, px + -1.0f, py + 0.0f);
+    float u12 = bilinear(g, m, px + 1.0f, py + 0.0f);
+    float u20 = bilinear(g, m, px + -1.0f, py + 1.0f);
+    float u21 = bilinear(g, m, px + 0.0f, py + 1.0f);
+    float u22 = bilinear(g, m, px + 1.0f, py + 1.0f);
     return mk(u00 + u10 + u10 + u20 - u02 - u12 - u12 - u22,
               u00 + u01 + u01 + u02 - u20 - u21 - u21 - u22);
 }
@@ -270,16 +293,17 @@ __device__ __forceinline__ AxisTaps axis_taps(float p)
 }
 
 // u[r][c] = bilinear(g, p + (c - 1, r - 1)); returns false when the patch form does not apply
-__device__ __forceinline__ bool stencil_taps(const float* __restrict__ g, int32_t rows, int32_t cols,
-                                             float px, float py, float (&u)[3][3])
+__device__ __forceinline__ bool stencil_taps(const float* __restrict__ g, const MapDims& m, float px,
+                                             float py, float (&u)[3][3])
 {
+    const int32_t cols = m.cols;
     AxisTaps ax = axis_taps(px), ay = axis_taps(py);
     int64_t x0 = ax.i[0], y0 = ay.i[0];
     if (ax.i[1] != x0 + 1 || ax.i[2] != x0 + 2 || ay.i[1] != y0 + 1 || ay.i[2] != y0 + 2)
         return false;
     float P[4][4];
-    if (x0 >= 0 && y0 >= 0 && x0 + 3 < cols && y0 + 3 < rows) {
-        const float* row = g + (size_t)y0 * (size_t)cols + (size_t)x0;
+    if (x0 >= 0 && y0 >= m.y_lo && x0 + 3 < cols && y0 + 3 < m.y_hi) {
+        const float* row = g + (y0 * (int64_t)cols + x0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -290,7 +314,7 @@ __device__ __forceinline__ bool stencil_taps(const float* __restrict__ g, int32_
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) P[r][c] = texel(g, rows, cols, x0 + c, y0 + r);
+            for (int c = 0; c < 4; ++c) P[r][c] = texel(g, m, x0 + c, y0 + r);
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -307,13 +331,13 @@ __device__ __forceinline__ bool stencil_taps(const float* __restrict__ g, int32_
 }
 
 // sobel_filter (util.rs:61-75) and, optionally, the centre sample (field.rs:242-245)
-__device__ __forceinline__ v2 sobel_fast(const float* __restrict__ g, int32_t rows, int32_t cols,
-                                         float px, float py, float* centre)
+__device__ __forceinline__ v2 sobel_fast(const float* __restrict__ g, const MapDims& m, float px, float py,
+                                         float* centre)
 {
     float u[3][3];
-    if (!stencil_taps(g, rows, cols, px, py, u)) {
-        if (centre) *centre = bilinear(g, rows, cols, px, py);
-        return sobel(g, rows, cols, px, py);
+    if (!stencil_taps(g, m, px, py, u)) {
+        if (centre) *centre = bilinear(g, m, px, py);
+        return sobel(g, m, px, py);
     }
     if (centre) *centre = u[1][1];
     return mk(u[0][0] + u[1][0] + u[1][0] + u[2][0] - u[0][2] - u[1][2] - u[1][2] - u[2][2],

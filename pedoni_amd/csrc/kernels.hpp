@@ -58,7 +58,7 @@ __device__ __forceinline__ bool survives(const FieldView& f, v2 pos, uint32_t de
 {
     if (dest >= f.n_maps) return false;
     v2 q = field_coord(f, pos);
-    return bilinear(f.potential_maps[dest], f.rows, f.cols, q.x, q.y) > 0.25f;
+    return bilinear(f.potential_maps[dest], dims_of(f), q.x, q.y) > 0.25f;
 }
 
 // ---- the sort/despawn pass (sfm.rs:58-77) on the device -----------------------------------
@@ -150,9 +150,10 @@ __global__ void key_kernel(const float2* __restrict__ pos, const uint32_t* __res
     if (own || received) {
         float2 p = pos[i];
         v2 pp = mk(p.x, p.y);
-        if (cell_xy(grid, pp, cx, cy) && survives(field, pp, dest[i])) {
-            // sharded runs keep only the band's rows plus one ghost row either side
-            if (cy >= band_lo - 1 && cy <= band_hi) {
+        // sharded runs keep only the band's rows plus one ghost row either side (tested before
+        // the potential is sampled: a band may hold only its own rows of the maps)
+        if (cell_xy(grid, pp, cx, cy) && cy >= band_lo - 1 && cy <= band_hi && survives(field, pp, dest[i])) {
+            {
                 k = (uint32_t)cy * (uint32_t)grid.cols + (uint32_t)cx;
                 // agents appended since the last pass force the general form -- except the
                 // exchanged lists of a sharded run, which can only land in the four boundary
@@ -534,7 +535,7 @@ template <int MODE>
 __device__ __forceinline__ v2 goal_direction(const FieldView& f, v2 pos, uint32_t dest)
 {
     v2 q = field_coord(f, pos);
-    v2 g = sobel_fast(f.potential_maps[dest], f.rows, f.cols, q.x, q.y, nullptr);
+    v2 g = sobel_fast(f.potential_maps[dest], dims_of(f), q.x, q.y, nullptr);
     return normalize<0>(g); // exact in both math modes: `e` feeds the field-of-view decision
 }
 
@@ -544,7 +545,7 @@ __device__ __forceinline__ v2 obstacle_force_map(const FieldView& f, v2 pos, con
 {
     v2 q = field_coord(f, pos);
     float distance;
-    v2 direction = -normalize<MODE>(sobel_fast(f.distance_map, f.rows, f.cols, q.x, q.y, &distance));
+    v2 direction = -normalize<MODE>(sobel_fast(f.distance_map, dims_of(f), q.x, q.y, &distance));
     float k = (10.0f * 0.2f) * fexp<MODE>(div_02<MODE>(-distance), tab);
     return direction * k;
 }
@@ -688,7 +689,7 @@ constexpr int FORCE_THREADS = 256;
 constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 
 template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
+__device__ __forceinline__ void force_queue_body(const ForceArgs& a)
 {
     __shared__ uint64_t tab[32];
     __shared__ float4 queue_all[FORCE_WAVES][SLOTS * 64];
@@ -878,8 +879,9 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
     if (a.key_next) {
         uint32_t k = DEAD;
         int32_t cx = 0, cy = 0;
-        if (cell_xy(a.grid, pos, cx, cy) && survives(a.field, pos, a.dest[id])) {
-            if (cy >= a.band_lo - 1 && cy <= a.band_hi) {
+        if (cell_xy(a.grid, pos, cx, cy) && cy >= a.band_lo - 1 && cy <= a.band_hi &&
+            survives(a.field, pos, a.dest[id])) {
+            {
                 k = (uint32_t)cy * (uint32_t)a.grid.cols + (uint32_t)cx;
                 if (abs(cx - ix) > 1 || abs(cy - iy) > 1) atomicOr(&a.flags->far[a.parity_next], 1u);
             }
@@ -887,6 +889,23 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
         a.key_next[id] = k;
         count_key(a.cell_count, a.row_count, k != DEAD, k, (uint32_t)cy);
     }
+}
+
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
+{
+    force_queue_body<MODE, SLOTS>(a);
+}
+
+// The same kernel held to 94 SGPRs: a CU admits floor(800 / (ceil(sgpr / 16) * 16 + 16)) 256-thread
+// workgroups (MI355X_MICROARCH.md, residency), i.e. 6 at the 97-112 the compiler uses by
+// default and 7 at <= 96 -- the 7th wave per SIMD that the <= 72 VGPRs and a 5-slot queue
+// (22 KB LDS per block) already allow.
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_s94(ForceArgs a)
+{
+    force_queue_body<MODE, SLOTS>(a);
 }
 
 // ---- on-device periodic spawning (Simulator::tick, lib.rs:67-85 + sfm.rs:49-56) ---------------
@@ -1075,8 +1094,8 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
         vel[at] = make_float2(__uint_as_float(src[2]), __uint_as_float(src[3]));
         v0[at] = __uint_as_float(src[4]);
         dest[at] = d;
-        if (cell_xy(grid, p, cx, cy) && survives(field, p, d)) {
-            if (cy >= band_lo - 1 && cy <= band_hi) {
+        if (cell_xy(grid, p, cx, cy) && cy >= band_lo - 1 && cy <= band_hi && survives(field, p, d)) {
+            {
                 kk = (uint32_t)cy * (uint32_t)grid.cols + (uint32_t)cx;
                 // exchanged agents belong in the four boundary rows (general sort form there);
                 // anywhere else the whole pass must take the general form

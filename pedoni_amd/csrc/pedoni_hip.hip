@@ -148,7 +148,7 @@ struct PedoniModel {
     bool sort_general = false; // PEDONI_SORT_GENERAL=1: always take the atomic (general) sort form
     bool no_fuse_key = false;  // PEDONI_NO_FUSE_KEY=1: standalone K_KEY every tick
     bool xcd_remap = true;     // PEDONI_NO_XCD_REMAP=1: hardware block order
-    int force_slots = 6;       // PEDONI_FORCE_SLOTS: candidates per lane per batch (6 or 8)
+    int force_slots = 0;       // PEDONI_FORCE_SLOTS: candidates per lane per batch (0 = by size; 4, 5, 6, 8)
 
     // steady-state tick pair captured as a hipGraph (pedoni_hip_tick_n); see tick_graph()
     hipGraphExec_t graph_exec = nullptr;
@@ -161,6 +161,9 @@ struct PedoniModel {
 
     // profiling
     uint32_t profile_mask = 0;
+    uint32_t profile_every = 1;   // tick_n: time the kernels of every n-th tick only
+    uint64_t tick_counter = 0;
+    bool profile_now = true;      // false while tick_n runs a tick that is not sampled
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
     PedoniKernelTimes times{};
@@ -196,7 +199,7 @@ struct Timed {
     int rc = PEDONI_OK;
     Timed(PedoniModel* m_, int kernel) : m(m_)
     {
-        if (kernel < 0 || !((m->profile_mask >> kernel) & 1u)) return;
+        if (kernel < 0 || !m->profile_now || !((m->profile_mask >> kernel) & 1u)) return;
         if (m->ev_used == m->ev_pool.size()) {
             if (m->ev_pool.size() >= 8192) {
                 rc = drain_events(m);
@@ -520,11 +523,25 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
     const bool fast = m->opt.math_mode == PEDONI_MATH_FAST;
     if (m->opt.use_neighbor_grid && !m->force_simple) {
         dim3 grid(blocks_for(n, FORCE_THREADS)), block(FORCE_THREADS);
-        // 6 candidate slots per lane and batch: 28 KB LDS per block -> 5 waves/SIMD; measured
-        // 0.145 ms at N = 1e6 against 0.151 (8 slots, 4 waves) and 0.22 (16 slots, 2 waves)
-        if (fast) hipLaunchKernelGGL((force_kernel_queue<1, 6>), grid, block, 0, stream, a);
-        else if (m->force_slots == 8) hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((force_kernel_queue<0, 6>), grid, block, 0, stream, a);
+        // candidate slots per lane and batch: 6 slots = 26 KB LDS per block = 6 workgroups per
+        // CU; 5 slots = 22 KB, which with the 94-SGPR build of the kernel lets a CU admit a 7th
+        // workgroup (7 waves/SIMD at 70 VGPRs).  Measured at N = 1e6, exact mode: 103.7 us with
+        // 5 slots / 7 waves against 106.6 us with 6 / 6; the fast mode and small crowds (whose
+        // waves are few anyway) do not gain, so they keep 6 slots -- fewer batches per wave.
+        int slots = m->force_slots;
+        if (slots == 0) slots = (!fast && n >= 400000u) ? 5 : 6;
+        switch (slots + (fast ? 100 : 0)) {
+        case 4: hipLaunchKernelGGL((force_kernel_queue_s94<0, 4>), grid, block, 0, stream, a); break;
+        case 5: hipLaunchKernelGGL((force_kernel_queue_s94<0, 5>), grid, block, 0, stream, a); break;
+        case 15: hipLaunchKernelGGL((force_kernel_queue<0, 5>), grid, block, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, stream, a); break;
+        case 104: hipLaunchKernelGGL((force_kernel_queue_s94<1, 4>), grid, block, 0, stream, a); break;
+        case 105: hipLaunchKernelGGL((force_kernel_queue_s94<1, 5>), grid, block, 0, stream, a); break;
+        case 108: hipLaunchKernelGGL((force_kernel_queue<1, 8>), grid, block, 0, stream, a); break;
+        default:
+            if (fast) hipLaunchKernelGGL((force_kernel_queue<1, 6>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((force_kernel_queue<0, 6>), grid, block, 0, stream, a);
+        }
     } else {
         if (part != 0) return fail(PEDONI_E_INVALID, "row-segment force launch needs the queue kernel");
         dim3 grid(blocks_for(n, bs)), block(bs);
@@ -566,6 +583,9 @@ int check_status(uint32_t status)
     if (status & STATUS_LIVE_OVERFLOW)
         return fail(PEDONI_E_CAPACITY, "device status: more live agents than the host's bound of the arrays "
                                        "(received lists larger than the reserved capacity?)");
+    if (status & STATUS_FIELD_SLICE)
+        return fail(PEDONI_E_CAPACITY, "device status: an agent sampled a field-map row outside the rows uploaded "
+                                       "for this band (pedoni_hip_create_rows: widen the row range)");
     if (status) return fail(PEDONI_E_HIP, "device status word is set: " + std::to_string(status));
     return PEDONI_OK;
 }
@@ -675,11 +695,23 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
                       const PedoniObstacle* obstacles, uint32_t n_obstacles, int device,
                       PedoniModel** out)
 {
+    return pedoni_hip_create_rows(opt, size_x, size_y, distance_map, potential_maps, n_maps, field_rows, field_cols,
+                                  field_unit, obstacles, n_obstacles, device, 0, field_rows, out);
+}
+
+int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
+                           const float* distance_map, const float* const* potential_maps,
+                           uint32_t n_maps, uint32_t field_rows, uint32_t field_cols, float field_unit,
+                           const PedoniObstacle* obstacles, uint32_t n_obstacles, int device,
+                           uint32_t map_row_begin, uint32_t map_row_end, PedoniModel** out)
+{
     if (!opt || !out) return fail(PEDONI_E_INVALID, "create: null options/out");
     if (!distance_map || (n_maps && !potential_maps))
         return fail(PEDONI_E_INVALID, "create: null field maps");
     if (field_rows == 0 || field_cols == 0 || field_rows > 0x7fffffffu || field_cols > 0x7fffffffu)
         return fail(PEDONI_E_INVALID, "create: bad field shape");
+    if (map_row_begin >= map_row_end || map_row_end > field_rows)
+        return fail(PEDONI_E_INVALID, "create: bad map row range");
     if (n_obstacles && !obstacles) return fail(PEDONI_E_INVALID, "create: null obstacles");
     if (opt->gpu_work_size < 0 || opt->gpu_work_size > 1024 || (opt->gpu_work_size % 64) != 0)
         return fail(PEDONI_E_INVALID, "create: gpu_work_size must be a multiple of 64 <= 1024");
@@ -723,21 +755,28 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
     C_HIP(hipEventCreateWithFlags(&m->ev_sorted, hipEventDisableTiming));
     C_HIP(hipEventCreateWithFlags(&m->ev_interior, hipEventDisableTiming));
 
-    // field maps
-    size_t texels = (size_t)field_rows * field_cols;
+    // field maps: the texel rows [map_row_begin, map_row_end) of every map go to the device; the
+    // pointers the kernels index are biased by -map_row_begin rows, so texel (y, x) stays at
+    // base[y * cols + x] (never dereferenced outside the slice: device_math.hpp FieldView)
+    const size_t slice_off = (size_t)map_row_begin * field_cols;
+    const size_t texels = (size_t)(map_row_end - map_row_begin) * field_cols;
     C_TRY(dev_alloc(&m->d_distance_map, texels));
-    C_HIP(hipMemcpy(m->d_distance_map, distance_map, texels * sizeof(float), hipMemcpyHostToDevice));
+    C_HIP(hipMemcpy(m->d_distance_map, distance_map + slice_off, texels * sizeof(float), hipMemcpyHostToDevice));
     m->d_pot.resize(n_maps, nullptr);
+    std::vector<const float*> biased(n_maps, nullptr);
     for (uint32_t k = 0; k < n_maps; ++k) {
         if (!potential_maps[k]) return bail(fail(PEDONI_E_INVALID, "create: null potential map"));
         C_TRY(dev_alloc(&m->d_pot[k], texels));
-        C_HIP(hipMemcpy(m->d_pot[k], potential_maps[k], texels * sizeof(float), hipMemcpyHostToDevice));
+        C_HIP(hipMemcpy(m->d_pot[k], potential_maps[k] + slice_off, texels * sizeof(float), hipMemcpyHostToDevice));
+        biased[k] = (const float*)((uintptr_t)m->d_pot[k] - slice_off * sizeof(float));
     }
     C_TRY(dev_alloc(&m->d_pot_ptrs, n_maps));
     if (n_maps)
-        C_HIP(hipMemcpy(m->d_pot_ptrs, m->d_pot.data(), n_maps * sizeof(float*), hipMemcpyHostToDevice));
-    m->field.distance_map = m->d_distance_map;
+        C_HIP(hipMemcpy(m->d_pot_ptrs, biased.data(), n_maps * sizeof(float*), hipMemcpyHostToDevice));
+    m->field.distance_map = (const float*)((uintptr_t)m->d_distance_map - slice_off * sizeof(float));
     m->field.potential_maps = m->d_pot_ptrs;
+    m->field.y_lo = (int32_t)map_row_begin;
+    m->field.y_hi = (int32_t)map_row_end;
     m->field.rows = (int32_t)field_rows;
     m->field.cols = (int32_t)field_cols;
     m->field.unit = field_unit;
@@ -782,6 +821,7 @@ int pedoni_hip_create(const PedoniOptions* opt, float size_x, float size_y,
 
     C_TRY(dev_alloc(&m->d_live, 4));
     C_HIP(hipMemset(m->d_live, 0, 4 * sizeof(uint32_t)));
+    m->field.status = m->d_live + 1;
     C_TRY(dev_alloc(&m->d_flags, 1));
     C_HIP(hipMemset(m->d_flags, 0, sizeof(SortFlags)));
     C_TRY(dev_alloc(&m->d_halo, 1));
@@ -898,7 +938,7 @@ namespace {
 bool graphable(const PedoniModel* m)
 {
     return m->use_graph && m->stream != nullptr && m->opt.use_neighbor_grid && !m->force_simple && !m->sort_general &&
-           !m->no_fuse_key && !m->n_spawners && !m->halo_cap && !m->profile_mask && m->have_old &&
+           !m->no_fuse_key && !m->n_spawners && !m->halo_cap && m->have_old &&
            m->keys_valid && !m->sorted && m->gap_end == m->n_upper && m->n_upper > m->base &&
            m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
 }
@@ -948,19 +988,28 @@ int tick_graph_pair(PedoniModel* m)
 int pedoni_hip_tick_n(PedoniModel* m, uint32_t steps)
 {
     TRY(bind(m));
+    // with profiling on, the kernels of every profile_every-th tick are event-timed (those
+    // ticks launch eagerly); all other ticks may replay the captured pair
+    auto sampled = [&](uint64_t t) { return m->profile_mask != 0 && t % m->profile_every == 0; };
     uint32_t s = 0;
-    while (s < steps) {
-        if (steps - s >= 2 && graphable(m)) {
-            TRY(tick_graph_pair(m));
+    int rc = PEDONI_OK;
+    while (s < steps && rc == PEDONI_OK) {
+        if (steps - s >= 2 && !sampled(m->tick_counter) && !sampled(m->tick_counter + 1) && graphable(m)) {
+            m->profile_now = false;
+            rc = tick_graph_pair(m);
             s += 2;
+            m->tick_counter += 2;
             continue;
         }
-        if (m->n_spawners) TRY(device_spawn(m));
-        TRY(sort_despawn(m));
-        TRY(update_states(m));
+        m->profile_now = sampled(m->tick_counter);
+        if (m->n_spawners) rc = device_spawn(m);
+        if (rc == PEDONI_OK) rc = sort_despawn(m);
+        if (rc == PEDONI_OK) rc = update_states(m);
         s += 1;
+        m->tick_counter += 1;
     }
-    return PEDONI_OK;
+    m->profile_now = true;
+    return rc;
 }
 
 int pedoni_hip_set_spawners(PedoniModel* m, const PedoniSpawner* spawners, uint32_t n,
@@ -1210,6 +1259,14 @@ int pedoni_hip_profile(PedoniModel* m, int32_t enable)
     return PEDONI_OK;
 }
 
+int pedoni_hip_profile_every(PedoniModel* m, uint32_t every_ticks)
+{
+    TRY(bind(m));
+    if (every_ticks == 0) return fail(PEDONI_E_INVALID, "profile_every: must be >= 1");
+    m->profile_every = every_ticks;
+    return PEDONI_OK;
+}
+
 int pedoni_hip_kernel_times(PedoniModel* m, PedoniKernelTimes* out, int32_t reset)
 {
     TRY(bind(m));
@@ -1448,7 +1505,9 @@ __global__ void selftest_field_kernel(const float* grid, int32_t rows, int32_t c
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float c;
-    v2 g = sobel_fast(grid, rows, cols, px[i], py[i], &c);
+    MapDims md;
+    md.rows = rows; md.cols = cols; md.y_lo = 0; md.y_hi = rows; md.status = nullptr;
+    v2 g = sobel_fast(grid, md, px[i], py[i], &c);
     grad[i] = make_float2(g.x, g.y);
     centre[i] = c;
 }

@@ -164,6 +164,16 @@ struct PedoniShard {
     uint32_t* d_bulk_recv[2] = {nullptr, nullptr}; // [0] from the band below, [1] from the band above
     // members of a local group (one process, one device) reach each other directly
     PedoniShard** group = nullptr;
+    // initial bounds and slack every rank's map slice was cut with (pedoni_shard_map_rows): a
+    // re-cut may move boundary b only where both adjoining bands still fit their slices
+    std::vector<int32_t> bounds0;
+    int32_t slice_slack = -1;          // < 0: whole maps on the device, no constraint
+    bool fits(int32_t b, int32_t to) const
+    {
+        if (slice_slack < 0) return true;
+        // band b-1 = [.., to) was cut for rows up to bounds0[b] + slack; band b = [to, ..) from bounds0[b] - slack
+        return to <= bounds0[b] + slice_slack && to >= bounds0[b] - slice_slack;
+    }
 };
 
 namespace {
@@ -240,6 +250,10 @@ void recut_bounds(const PedoniShard* s, const uint32_t* hist, std::vector<int32_
         want = std::max(want, std::max(s->bounds[b - 1] + min_rows, nb[b - 1] + min_rows));
         want = std::min(want, s->bounds[b + 1] - min_rows);
         if (want < nb[b - 1] + min_rows) want = old;      // cannot satisfy both: leave it
+        // a band that holds only a slice of the field maps must stay inside it (both bands that
+        // meet at this boundary are checked by their own ranks alike: the slices are symmetric
+        // functions of the initial bounds, so every rank evaluates the same predicate)
+        while (want != old && !s->fits(b, want)) want += want < old ? 1 : -1;
         // the rows handed over must fit one bulk list
         auto moved = [&](int32_t to) {
             uint64_t n = 0;
@@ -379,6 +393,22 @@ int pedoni_shard_unique_id(uint8_t id[PEDONI_SHARD_ID_BYTES])
     return PEDONI_OK;
 }
 
+int pedoni_shard_map_rows(int32_t row_begin, int32_t row_end, int32_t slack_rows, float neighbor_grid_unit,
+                          float field_unit, uint32_t field_rows, uint32_t* map_row_begin, uint32_t* map_row_end)
+{
+    if (!map_row_begin || !map_row_end || row_begin >= row_end || slack_rows < 0 || !(neighbor_grid_unit > 0.0f) ||
+        !(field_unit > 0.0f) || field_rows == 0)
+        return fail(PEDONI_E_INVALID, "shard_map_rows: bad arguments");
+    // agents of the band sit in grid rows row_begin-1 .. row_end (ghost rows included) and step at
+    // most one more row per tick; every sample point p / unit - 0.5 is the centre of a 4 x 4 patch
+    const double y0 = (double)(row_begin - 2 - slack_rows) * neighbor_grid_unit;
+    const double y1 = (double)(row_end + 2 + slack_rows) * neighbor_grid_unit;
+    const double t0 = std::floor(y0 / field_unit - 0.5) - 3.0, t1 = std::ceil(y1 / field_unit - 0.5) + 4.0;
+    *map_row_begin = (uint32_t)std::max(0.0, std::min(t0, (double)field_rows - 1.0));
+    *map_row_end = (uint32_t)std::max((double)*map_row_begin + 1.0, std::min(t1, (double)field_rows));
+    return PEDONI_OK;
+}
+
 int pedoni_shard_balanced_bounds(const uint32_t* row_counts, uint32_t n_rows, int32_t world, int32_t min_rows,
                                  int32_t* bounds_out)
 {
@@ -417,6 +447,7 @@ int pedoni_shard_create(PedoniModel* m, int32_t rank, int32_t world, const uint8
     s->rank = rank;
     s->world = world;
     s->bounds.assign(row_bounds, row_bounds + world + 1);
+    s->bounds0 = s->bounds;
     s->cap = halo_cap;
     s->words_each = PEDONI_HALO_HEADER_WORDS + halo_cap * PEDONI_HALO_RECORD_WORDS;
     auto bail = [&](int rc) { pedoni_shard_destroy(s); return rc; };
@@ -488,12 +519,24 @@ int pedoni_shard_band(PedoniShard* s, int32_t* row_begin, int32_t* row_end)
     return PEDONI_OK;
 }
 
-int pedoni_shard_set_rebalance(PedoniShard* s, uint32_t every_ticks, uint32_t max_rows_per_step)
+int pedoni_shard_set_rebalance(PedoniShard* s, uint32_t every_ticks, uint32_t max_rows_per_step,
+                               int32_t map_slack_rows)
 {
     TRY(shard_check(s));
     PedoniModel* m = s->m;
     if (every_ticks && (max_rows_per_step == 0 || max_rows_per_step > 64))
         return fail(PEDONI_E_INVALID, "set_rebalance: max_rows_per_step must be 1 .. 64");
+    const bool whole_maps = m->field.y_lo == 0 && m->field.y_hi == m->field.rows;
+    if (every_ticks && map_slack_rows < 0 && !whole_maps)
+        return fail(PEDONI_E_INVALID, "set_rebalance: this model holds a slice of the field maps; state the slack it was cut with");
+    if (every_ticks && map_slack_rows >= 0) {
+        uint32_t a = 0, b = 0;
+        TRY(pedoni_shard_map_rows(s->bounds0[s->rank], s->bounds0[s->rank + 1], map_slack_rows, m->grid.unit,
+                                  m->field.unit, (uint32_t)m->field.rows, &a, &b));
+        if ((int32_t)a < m->field.y_lo || (int32_t)b > m->field.y_hi)
+            return fail(PEDONI_E_INVALID, "set_rebalance: the model's field-map rows do not cover its band plus that slack");
+    }
+    s->slice_slack = map_slack_rows;
     s->rebalance_every = every_ticks;
     if (!every_ticks) return PEDONI_OK;
     s->max_shift = max_rows_per_step;

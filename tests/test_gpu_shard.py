@@ -63,14 +63,21 @@ def test_local_group_equals_single_model_bitwise(hip, oracle, world, balanced, r
     assert row_counts.sum() == single.get_pedestrian_count()
     bounds = abi.balanced_bounds(row_counts, world) if balanced else [(rows * r) // world for r in range(world + 1)]
 
+    # every band holds only ITS texel rows of the field maps (pedoni_hip_create_rows), with room
+    # for the re-cut to move the band by up to `slack` grid rows
+    slack = 12 if rebalance_every else 0
     stream = torch.cuda.current_stream().cuda_stream
-    models = [make() for _ in range(world)]
-    shards = []
-    for r, m in enumerate(models):
+    models, shards = [], []
+    for r in range(world):
+        rows_needed = abi.shard_map_rows(bounds[r], bounds[r + 1], slack, 1.4, field.unit, field.shape[0])
+        m = hip.HipModel(hip.Options(), sc.field.size, field.distance_map, field.potential_maps, field.unit,
+                         sc.obstacle_array(), map_rows=rows_needed)
+        assert rows_needed[1] - rows_needed[0] < field.shape[0] * (0.75 if world > 3 else 0.9)
+        models.append(m)
         m.set_stream(stream)
         shards.append(abi.Shard(m, r, world, bounds, CAP))
         if rebalance_every:
-            shards[-1].set_rebalance(rebalance_every, 3)
+            shards[-1].set_rebalance(rebalance_every, 3, map_slack_rows=slack)
     band_of = np.searchsorted(np.asarray(bounds[1:-1]),
                               np.trunc(pos[:, 1] / np.float32(1.4)).astype(np.int64), side="right")
     for r, (m, s) in enumerate(zip(models, shards)):
@@ -168,3 +175,26 @@ def test_one_rank_rccl_group_runs_the_direct_calls(hip, oracle):
     assert s.owned_count() == single.get_pedestrian_count() == len(a[0])
     assert all(bit_equal(x, y).all() for x, y in zip(a, b))
     s.close(); m.close(); single.close()
+
+
+def test_sampling_outside_the_uploaded_map_rows_is_loud_not_a_fault(hip, oracle):
+    """A model that holds only a slice of the field maps never reads outside it: the sample
+    returns the out-of-field value and the sticky device status makes the next read of device
+    state fail (PEDONI_E_CAPACITY), instead of an out-of-bounds access."""
+    sc = _tall_box(60.0, 120.0)
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 4000, 2, seed=3)
+    lower = pos[:, 1] < 50.0
+    m = hip.HipModel(hip.Options(), sc.field.size, field.distance_map, field.potential_maps, field.unit,
+                     sc.obstacle_array(), map_rows=(0, 240))          # texel rows of y < 60 m only
+    m.append(pos[lower], dest[lower], v0[lower], vel[lower])
+    m.tick_n(3)
+    assert m.get_pedestrian_count() > 0                               # inside the slice: fine
+    m.append(pos[~lower][:10], dest[~lower][:10], v0[~lower][:10], vel[~lower][:10])
+    m.tick_n(1)
+    with pytest.raises(abi.PedoniError, match="field-map row"):
+        m.get_pedestrian_count()
+    m.close()
+    with pytest.raises(abi.PedoniError, match="map row range"):
+        hip.HipModel(hip.Options(), sc.field.size, field.distance_map, field.potential_maps, field.unit,
+                     sc.obstacle_array(), map_rows=(10, 10))

@@ -24,10 +24,22 @@ def _declared(header: str, prefix: str):
     return sorted(set(re.findall(rf"\b({prefix}_[a-z_0-9]+)\s*\(", text)))
 
 
+def test_balanced_bounds_is_pure_host_code():
+    """pedoni_shard_balanced_bounds needs no device: bands cut by agents, not rows."""
+    counts = np.array([1000] * 10 + [10] * 90, np.uint32)
+    b = abi.balanced_bounds(counts, 4, min_rows=2)
+    assert b[0] == 0 and b[-1] == 100 and all(b[i + 1] - b[i] >= 2 for i in range(4))
+    loads = [int(counts[b[i]:b[i + 1]].sum()) for i in range(4)]
+    assert max(loads) <= 1.3 * sum(loads) / 4, loads
+    assert abi.balanced_bounds(np.full(715, 1400, np.uint32), 8) == [0, 89, 178, 268, 357, 446, 536, 625, 715]
+    with pytest.raises(abi.PedoniError, match="world"):
+        abi.balanced_bounds(counts, 60, min_rows=2)
+
+
 def test_hip_library_exports_every_declared_symbol():
     lib = abi.load_library()
-    declared = _declared("pedoni_hip.h", "pedoni_hip")
-    assert declared, "header parse failed"
+    declared = _declared("pedoni_hip.h", "pedoni_(?:hip|shard)")
+    assert declared and any(d.startswith("pedoni_shard_") for d in declared), "header parse failed"
     assert sorted(abi.SYMBOLS) == declared, "abi.SYMBOLS out of sync with include/pedoni_hip.h"
     for name in declared:
         assert hasattr(lib, name), f"libpedoni_hip.so lacks {name}"

@@ -6,7 +6,8 @@ ROOT=$(pwd); OUT=$ROOT/gpurun_out/ab_$TAG; mkdir -p "$OUT"
 BASE="-O3 -std=c++17 -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -shared -fPIC -I$ROOT/include -I$ROOT/pedoni_amd/csrc -I/opt/rocm/include"
 i=0
 for FLAGS in "" "$@"; do
-    LIB=/tmp/libpedoni_hip_$i.so
+    mkdir -p /tmp/ab_$i; cp $ROOT/pedoni_amd/lib/libpedoni_host.so /tmp/ab_$i/   # resolves its libpedoni_hip.so via $ORIGIN
+    LIB=/tmp/ab_$i/libpedoni_hip.so
     hipcc $BASE $FLAGS -o $LIB $ROOT/pedoni_amd/csrc/pedoni_hip.hip -ldl > "$OUT/build_$i.log" 2>&1 || { echo "variant $i ($FLAGS): build failed"; i=$((i+1)); continue; }
     for MODE in exact fast; do
         PEDONI_HIP_LIB=$LIB python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --math $MODE > "$OUT/bench_${i}_$MODE.json" 2> "$OUT/bench_${i}_$MODE.err"

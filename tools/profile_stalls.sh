@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/stalls_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-B="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-profile $*"
+B="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-profile --no-fast-leg $*"
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1 || true
 pass() {
     name=$1; shift

@@ -24,12 +24,22 @@ def main():
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # launch durations from the kernel traces of the same (profiled) passes
+    dur = collections.defaultdict(list)
+    for f in glob.glob(f"{out_dir}/**/*_kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            dur[name].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     res = {}
     for k, cs in agg.items():
         if not k.startswith("pedoni::"):
             continue
         d = {c: sum(v) / len(v) for c, v in cs.items()}
         d["launches_seen"] = max(len(v) for v in cs.values())
+        if dur.get(k):
+            d["profiled_launch_us"] = sum(dur[k]) / len(dur[k]) / 1e3
+            if d.get("GRBM_GUI_ACTIVE"):      # rocprofv3 sums the 8 XCDs (MI355X_MICROARCH.md, DVFS)
+                d["clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / (d["profiled_launch_us"] * 1e3)
         wc = d.get("SQ_WAVE_CYCLES")
         if wc:
             for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
