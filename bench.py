@@ -273,15 +273,21 @@ def main() -> None:
     opt = abi.Options(math_mode=abi.MATH_FAST if args.math == "fast" else abi.MATH_EXACT,
                       gpu_work_size=args.work_size, initial_capacity=int(n_per * 1.3),
                       use_distance_map=args.workload != "c4seg")
+    map_rows = bounds = None
+    if G > 1 or force_sharded:
+        from pedoni_amd.sharded import ShardedModel, band_rows, default_halo_cap
+        rows = int(np.ceil(np.float32(height) / np.float32(opt.neighbor_grid_unit)))   # neighbor_grid.rs:14-20
+        bounds = band_rows(rows, G)                # uniform crowd: equal rows = equal agents
+        # each rank uploads only its band's texel rows of the three maps (1/G of 0.5 GB each at G = 8)
+        map_rows = abi.shard_map_rows(bounds[rank], bounds[rank + 1], 0, opt.neighbor_grid_unit, field.unit,
+                                      field.shape[0])
     model = abi.HipModel(opt, (width, height), field.distance_map, field.potential_maps,
-                         field.unit, obstacles, device=local_rank)
+                         field.unit, obstacles, device=local_rank, map_rows=map_rows)
 
     exchange = None
     if G > 1 or force_sharded:
-        from pedoni_amd.sharded import ShardedModel, band_rows, default_halo_cap
         model.set_stream(stream.cuda_stream)
-        rows, _ = model.neighbor_grid_shape()
-        bounds = band_rows(rows, G)                # uniform crowd: equal rows = equal agents
+        assert model.neighbor_grid_shape()[0] == rows
         cap = default_halo_cap(int(width * 1.4 * density))
         runner = shard = None
         if os.environ.get("PEDONI_EXCHANGE", "rccl") == "rccl" and dist.get_backend() == "nccl":
@@ -310,7 +316,7 @@ def main() -> None:
                 shard = None
                 model.close()
                 model = abi.HipModel(opt, (width, height), field.distance_map, field.potential_maps,
-                                     field.unit, obstacles, device=local_rank)
+                                     field.unit, obstacles, device=local_rank, map_rows=map_rows)
                 model.set_stream(stream.cuda_stream)
         if shard is None:
             runner = ShardedModel(model, rank, G, dist, torch, halo_cap=cap, bounds=bounds,

@@ -281,6 +281,15 @@ int pedoni_shard_set_rebalance(PedoniShard* s, uint32_t every_ticks, uint32_t ma
  * lockstep. */
 int pedoni_shard_local_group_tick_n(PedoniShard** shards, uint32_t n_shards, uint32_t steps);
 
+/* [ext] opt-in GPU builder of the field maps (no bit parity with upstream's
+ * heap fast marching, field.rs:118-192, whose numbers depend on its pop order): solves
+ * |grad u| = f on a rows x cols grid by a block fast iterative method on the first-order upwind
+ * update.  `potential` (host, in/out): 0 on the zero set, >= 1e23 elsewhere; `slowness`: one f
+ * per cell (host) or NULL for the constant `uniform_slowness`.  pedoni_field_build_gpu
+ * (pedoni_host.h) wraps it into Field::from_scenario's shape. */
+int pedoni_hip_eikonal(int device, float* potential, const float* slowness, float uniform_slowness,
+                       uint32_t rows, uint32_t cols, uint32_t* launches_out);
+
 /* [ext] test hook: overwrite the model's sticky device status word (the word the scan and
  * place kernels raise when cell and row counts disagree or the live count exceeds the host's
  * bound of the arrays).  While it is non-zero every read of device state -- get_pedestrian_count,

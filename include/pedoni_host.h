@@ -66,6 +66,15 @@ int pedoni_field_from_scenario(const PedoniScenario* s, float unit, PedoniField*
 int pedoni_field_build(float size_x, float size_y, float unit, const PedoniObstacle* obstacles,
                        uint32_t n_obstacles, const PedoniObstacle* waypoints,
                        uint32_t n_waypoints, PedoniField** out);
+/* [ext] opt-in, NOT the reference's numbers: the same rasterisation, the maps by the GPU eikonal
+ * solver (pedoni_hip_eikonal: block fast iterative method on the first-order upwind scheme)
+ * instead of upstream's heap pass (field.rs:118-192), whose result depends on its pop order and
+ * cannot be reproduced in parallel.  For start-up time on large fields; the parity tests of the
+ * per-step path never use it.  `launches` (may be NULL) receives the relaxation launches run. */
+int pedoni_field_build_gpu(float size_x, float size_y, float unit, const PedoniObstacle* obstacles,
+                           uint32_t n_obstacles, const PedoniObstacle* waypoints,
+                           uint32_t n_waypoints, int32_t device, uint32_t* launches,
+                           PedoniField** out);
 void pedoni_field_free(PedoniField* f);
 int pedoni_field_shape(const PedoniField* f, uint32_t* rows, uint32_t* cols, uint32_t* n_maps,
                        float* unit);

@@ -40,7 +40,7 @@ SYMBOLS = [
     "pedoni_hip_owned_count",
     "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_selftest_field", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
     "pedoni_hip_debug_set_status", "pedoni_hip_profile_every",
-    "pedoni_hip_create_rows", "pedoni_shard_map_rows",
+    "pedoni_hip_create_rows", "pedoni_shard_map_rows", "pedoni_hip_eikonal",
     "pedoni_shard_unique_id", "pedoni_shard_balanced_bounds", "pedoni_shard_create", "pedoni_shard_destroy",
     "pedoni_shard_begin", "pedoni_shard_tick_n", "pedoni_shard_owned_count", "pedoni_shard_band",
     "pedoni_shard_selftest", "pedoni_shard_set_rebalance", "pedoni_shard_local_group_tick_n",
@@ -514,3 +514,20 @@ def local_group_tick_n(shards: Sequence[Shard], steps: int) -> None:
     lib = shards[0]._lib
     arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
     _check(lib, lib.pedoni_shard_local_group_tick_n(arr, C.c_uint32(len(shards)), C.c_uint32(steps)))
+
+
+def eikonal(potential: np.ndarray, slowness, device: int = 0):
+    """pedoni_hip_eikonal on a (rows, cols) f32 array (0 on the zero set, >= 1e23 elsewhere);
+    `slowness` = per-cell array or a float.  Returns (solution, relaxation launches)."""
+    lib = load_library()
+    u = np.array(potential, np.float32, copy=True, order="C")
+    n = C.c_uint32(0)
+    if np.isscalar(slowness):
+        fptr, uni = None, float(slowness)
+    else:
+        f = np.ascontiguousarray(slowness, np.float32)
+        assert f.shape == u.shape
+        fptr, uni = f.ctypes.data_as(C.POINTER(C.c_float)), 0.0
+    _check(lib, lib.pedoni_hip_eikonal(C.c_int(device), u.ctypes.data_as(C.POINTER(C.c_float)), fptr,
+                                       C.c_float(uni), C.c_uint32(u.shape[0]), C.c_uint32(u.shape[1]), C.byref(n)))
+    return u, int(n.value)

@@ -139,6 +139,34 @@ int pedoni_field_build(float size_x, float size_y, float unit, const PedoniObsta
     });
 }
 
+int pedoni_field_build_gpu(float size_x, float size_y, float unit, const PedoniObstacle* obstacles,
+                           uint32_t n_obstacles, const PedoniObstacle* waypoints, uint32_t n_waypoints,
+                           int32_t device, uint32_t* launches, PedoniField** out)
+{
+    if (!out || (n_obstacles && !obstacles) || (n_waypoints && !waypoints))
+        return fail(PEDONI_E_INVALID, "null argument");
+    return guarded([&] {
+        Scenario sc;
+        sc.field.size = Vec2{size_x, size_y};
+        for (uint32_t i = 0; i < n_obstacles; ++i) {
+            ObstacleConfig c;
+            c.line[0] = Vec2{obstacles[i].x0, obstacles[i].y0};
+            c.line[1] = Vec2{obstacles[i].x1, obstacles[i].y1};
+            c.width = obstacles[i].width;
+            sc.obstacles.push_back(c);
+        }
+        for (uint32_t i = 0; i < n_waypoints; ++i) {
+            WaypointConfig c;
+            c.line[0] = Vec2{waypoints[i].x0, waypoints[i].y0};
+            c.line[1] = Vec2{waypoints[i].x1, waypoints[i].y1};
+            c.width = waypoints[i].width;
+            sc.waypoints.push_back(c);
+        }
+        *out = new PedoniField{Field::from_scenario_gpu(sc, unit, device, launches)};
+        return PEDONI_OK;
+    });
+}
+
 void pedoni_field_free(PedoniField* f) { delete f; }
 
 int pedoni_field_shape(const PedoniField* f, uint32_t* rows, uint32_t* cols, uint32_t* n_maps, float* unit)

@@ -233,7 +233,16 @@ void apply_fmm(std::vector<float>& pot, const std::vector<float>& f, size_t rows
     }
 }
 
-Field Field::from_scenario(const Scenario& scenario, float unit)
+Field Field::from_scenario(const Scenario& scenario, float unit) { return build(scenario, unit, false, 0, nullptr); }
+
+// Opt-in, NOT the reference's numbers: the same rasterisation, then the maps by the parallel
+// eikonal solver of libpedoni_hip (pedoni_amd/csrc/eikonal.hpp) instead of the heap pass.
+Field Field::from_scenario_gpu(const Scenario& scenario, float unit, int device, uint32_t* launches)
+{
+    return build(scenario, unit, true, device, launches);
+}
+
+Field Field::build(const Scenario& scenario, float unit, bool gpu, int device, uint32_t* launches)
 {
     if (!(unit > 0.0f)) throw std::runtime_error("Field::from_scenario: unit must be > 0");
     Field fld;
@@ -271,6 +280,18 @@ Field Field::from_scenario(const Scenario& scenario, float unit)
     for (size_t i = 0; i < n; ++i) {
         fld.distance_map[i] = fld.obstacle_exist[i] ? 0.0f : 1e24f;
         slow_obs[i] = unit * (fld.obstacle_exist[i] ? 1e6f : 1.0f);
+    }
+    if (gpu) {
+        uint32_t total = 0, k = 0;
+        auto solve = [&](std::vector<float>& u, const float* slowness, float uniform) {
+            if (pedoni_hip_eikonal(device, u.data(), slowness, uniform, (uint32_t)rows, (uint32_t)cols, &k) != PEDONI_OK)
+                throw std::runtime_error(std::string("Field::from_scenario_gpu: ") + pedoni_hip_last_error());
+            total += k;
+        };
+        solve(fld.distance_map, nullptr, unit);
+        for (auto& pm : fld.potential_maps) solve(pm, slow_obs.data(), 0.0f);
+        if (launches) *launches = total;
+        return fld;
     }
     std::vector<std::thread> workers;
     workers.emplace_back([&] { apply_fmm(fld.distance_map, slow_free, rows, cols); });

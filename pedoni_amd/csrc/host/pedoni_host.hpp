@@ -68,10 +68,15 @@ struct Field {                  // field.rs:194-205
     std::vector<std::vector<float>> potential_maps;
 
     static Field from_scenario(const Scenario& scenario, float unit); // field.rs:220-232
+    // build-owned, opt-in: the maps by the GPU eikonal solver (NOT upstream's heap-order numbers)
+    static Field from_scenario_gpu(const Scenario& scenario, float unit, int device = 0, uint32_t* launches = nullptr);
     float get_potential(size_t waypoint_id, Vec2 position) const;     // field.rs:235-239
     float get_obstacle_distance(Vec2 position) const;                 // field.rs:242-245
     Vec2 get_potential_grad(size_t waypoint_id, Vec2 position) const; // field.rs:248-252
     Vec2 get_obstacle_distance_grad(Vec2 position) const;             // field.rs:255-258
+
+private:
+    static Field build(const Scenario& scenario, float unit, bool gpu, int device, uint32_t* launches);
 };
 
 namespace util {                // util.rs

@@ -1615,3 +1615,6 @@ extern "C" int pedoni_hip_selftest_math(int device, int32_t op, int32_t math_mod
 
 // ---- multi-GPU driver (pedoni_shard_*) ---------------------------------------------------------
 #include "shard.hpp"
+
+// ---- opt-in GPU field builder (pedoni_hip_eikonal) -----------------------------------------------
+#include "eikonal.hpp"

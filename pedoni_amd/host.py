@@ -20,7 +20,7 @@ SYMBOLS = [
     "pedoni_host_last_error", "pedoni_simulator_default_options", "pedoni_scenario_parse",
     "pedoni_scenario_free", "pedoni_scenario_size", "pedoni_scenario_segments",
     "pedoni_scenario_pedestrians", "pedoni_field_from_scenario", "pedoni_field_build",
-    "pedoni_field_free", "pedoni_field_shape", "pedoni_field_distance_map",
+    "pedoni_field_build_gpu", "pedoni_field_free", "pedoni_field_shape", "pedoni_field_distance_map",
     "pedoni_field_potential_map", "pedoni_field_obstacle_exist", "pedoni_field_get_potential",
     "pedoni_field_get_obstacle_distance", "pedoni_simulator_new", "pedoni_simulator_free",
     "pedoni_simulator_tick", "pedoni_simulator_tick_n", "pedoni_simulator_step", "pedoni_simulator_list_pedestrians",
@@ -171,11 +171,25 @@ class Field:
         return cls(h)
 
     @classmethod
-    def build(cls, size, unit: float, obstacles, waypoints) -> "Field":
+    def build(cls, size, unit: float, obstacles, waypoints, solver: str = "heap", device: int = 0) -> "Field":
+        """solver="heap": upstream's fast marching, pop order and all (field.rs:118-192) -- the
+        parity path.  solver="gpu": opt-in parallel eikonal solver (pedoni_field_build_gpu):
+        the scheme's fixed point, NOT upstream's numbers; `.gpu_launches` holds its launch count."""
         lib = load_library()
         obs = np.ascontiguousarray(obstacles, np.float32).reshape(-1, 5)
         wps = np.ascontiguousarray(waypoints, np.float32).reshape(-1, 5)
         h = C.c_void_p(None)
+        if solver == "gpu":
+            n = C.c_uint32(0)
+            _check(lib.pedoni_field_build_gpu(
+                C.c_float(size[0]), C.c_float(size[1]), C.c_float(unit),
+                obs.ctypes.data_as(C.c_void_p), C.c_uint32(len(obs)),
+                wps.ctypes.data_as(C.c_void_p), C.c_uint32(len(wps)), C.c_int32(device), C.byref(n), C.byref(h)))
+            f = cls(h)
+            f.gpu_launches = int(n.value)
+            return f
+        if solver != "heap":
+            raise PedoniError(f"unknown field solver {solver!r}")
         _check(lib.pedoni_field_build(
             C.c_float(size[0]), C.c_float(size[1]), C.c_float(unit),
             obs.ctypes.data_as(C.c_void_p), C.c_uint32(len(obs)),
