@@ -383,10 +383,28 @@ __device__ __forceinline__ float div_core(float n, Recip r)
 // ---- pair force (sfm.rs:131-153) -----------------------------------------------------
 #define PEDONI_COS_PHI (-0.17364817766693036f) /* sfm.rs:16 */
 
+// |v_i| * 0.1 of sfm.rs:144 depends on the NEIGHBOUR only, and every agent is a neighbour in
+// ~13 pairs per tick: it is computed once per agent, by the sort pass that moves the agent
+// (place / reorder kernels), and stored beside its velocity ({vx, vy, vl, desired_speed}).
+//   MODE 0: sqrt_core(|v|^2) * 0.1 -- the very operations pair_force_hot ran per pair -- when
+//           |v|^2 lies in the hot form's range [2^-96, 2^40); otherwise -1: a negative vl
+//           sends the pair to the generic path, which recomputes from the velocity itself
+//   MODE 1: v_sqrt_f32(|v|^2) * 0.1, what the fast pair force computed inline
+template <int MODE> __device__ __forceinline__ float neighbour_vl(v2 vel_i)
+{
+    const float v_sq = dot(vel_i, vel_i);
+    if constexpr (MODE == 0) {
+        if (sqrt_core_measure(v_sq) < 0x44000000u) return sqrt_core(v_sq) * 0.1f;
+        return -1.0f;
+    } else {
+        return __builtin_amdgcn_sqrtf(v_sq) * 0.1f;
+    }
+}
+
 // force on an agent from a neighbour, given difference = pos - pos_i with
 // |difference|^2 <= 4 already established (sfm.rs:137-153), before the field-of-view test
 template <int MODE>
-__device__ __forceinline__ v2 pair_force_raw(v2 difference, v2 vel_i, const uint64_t* tab,
+__device__ __forceinline__ v2 pair_force_raw(v2 difference, v2 vel_i, float vl_pre, const uint64_t* tab,
                                              bool& ill_conditioned)
 {
     float distance_squared = dot(difference, difference); // :132
@@ -396,7 +414,9 @@ __device__ __forceinline__ v2 pair_force_raw(v2 difference, v2 vel_i, const uint
     v2 t1 = difference - vel_i * 0.1f;                   // :141
     float t1_length = length<MODE>(t1);                  // :142
     float t2 = distance + t1_length;                     // :143
-    float vl = length<MODE>(vel_i) * 0.1f;
+    float vl;
+    if constexpr (MODE == 0) vl = length<0>(vel_i) * 0.1f;   // generic exact path: from the velocity itself
+    else vl = vl_pre;                                        // neighbour_vl<1>: the same v_sqrt_f32 * 0.1
     float t2_sq = t2 * t2, b_arg = t2_sq - vl * vl;
     // a neighbour about to step onto the agent: t2 -> |v| dt and the difference cancels
     ill_conditioned = !(b_arg * 8.0f > t2_sq);
@@ -415,7 +435,7 @@ __device__ __forceinline__ v2 pair_force_raw(v2 difference, v2 vel_i, const uint
 // div_core, the fma form of x / 0.3 and exp_glibc_core ARE the generic functions.  A pair
 // with anything else (zero velocity, coincident agents, NaN, ...) returns
 // worst >= SQRT_CORE_SPAN and is evaluated by the generic path instead.
-__device__ __forceinline__ uint32_t pair_force_hot(v2 difference, v2 e, v2 vel_i, const uint64_t* tab,
+__device__ __forceinline__ uint32_t pair_force_hot(v2 difference, v2 e, v2 vel_i, float vl, const uint64_t* tab,
                                                    v2& force, float& lhs, float& rhs)
 {
     float distance_squared = dot(difference, difference); // :132
@@ -428,12 +448,10 @@ __device__ __forceinline__ uint32_t pair_force_hot(v2 difference, v2 e, v2 vel_i
     worst = max(worst, sqrt_core_measure(t1_sq));
     float t1_length = sqrt_core(t1_sq);                  // :142
     float t2 = distance + t1_length;                     // :143
-    float v_sq = dot(vel_i, vel_i);
-    // |v| in [2^-48, 2^20): keeps every numerator and denominator below within 2^+-96 of
-    // each other (saturating add: an argument below 2^-96 has wrapped to a huge measure)
-    worst = max(worst, __builtin_elementwise_add_sat(sqrt_core_measure(v_sq),
-                                                     SQRT_CORE_SPAN - 0x44000000u));
-    float vl = sqrt_core(v_sq) * 0.1f;
+    // vl = neighbour_vl<0>(vel_i): sqrt_core(|v|^2) * 0.1 with |v| in [2^-48, 2^20) -- which keeps
+    // every numerator and denominator below within 2^+-96 of each other -- or -1 (sign bit set:
+    // a huge measure) when |v|^2 is outside that range
+    worst = max(worst, __float_as_uint(vl));
     float b_arg = t2 * t2 - vl * vl;
     worst = max(worst, sqrt_core_measure(b_arg));
     float b = sqrt_core(b_arg) * 0.5f;                   // :144
@@ -471,26 +489,26 @@ __device__ __forceinline__ uint32_t pair_force_hot(v2 difference, v2 e, v2 vel_i
 // 1-ulp error of sqrt/rcp would be amplified up to 1000-fold.  The goal direction `e` is
 // exact in both modes.  Every agent then meets the 1e-5 bar; no decision flips.
 template <int MODE>
-__device__ __forceinline__ void pair_force_from_difference(v2 difference, v2 e, v2 vel_i, v2& acc,
+__device__ __forceinline__ void pair_force_from_difference(v2 difference, v2 e, v2 vel_i, float vl, v2& acc,
                                                            const uint64_t* tab)
 {
     bool redo;
     v2 force;
     float lhs, rhs;
     if constexpr (MODE == 0) {
-        if (__builtin_expect(pair_force_hot(difference, e, vel_i, tab, force, lhs, rhs) >= SQRT_CORE_SPAN, 0)) {
-            force = pair_force_raw<0>(difference, vel_i, tab, redo);
+        if (__builtin_expect(pair_force_hot(difference, e, vel_i, vl, tab, force, lhs, rhs) >= SQRT_CORE_SPAN, 0)) {
+            force = pair_force_raw<0>(difference, vel_i, vl, tab, redo);
             lhs = dot(e, -force);
             rhs = length<0>(force) * PEDONI_COS_PHI;
         }
     } else {
-        force = pair_force_raw<MODE>(difference, vel_i, tab, redo);
+        force = pair_force_raw<MODE>(difference, vel_i, vl, tab, redo);
         float len = length<MODE>(force);
         lhs = dot(e, -force);
         rhs = len * PEDONI_COS_PHI;
         // ambiguous (or NaN) field-of-view test, or a cancelling b: evaluate exactly
         if (redo || !(__builtin_fabsf(lhs - rhs) > 1e-4f * len)) {
-            force = pair_force_raw<0>(difference, vel_i, tab, redo);
+            force = pair_force_raw<0>(difference, vel_i, vl, tab, redo);
             lhs = dot(e, -force);
             rhs = length<0>(force) * PEDONI_COS_PHI;
         }
@@ -507,7 +525,7 @@ __device__ __forceinline__ void pair_force(v2 pos, v2 e, v2 pos_i, v2 vel_i, v2&
     v2 difference = pos - pos_i;                         // :131
     float distance_squared = dot(difference, difference); // :132
     if (distance_squared > 4.0f) return;                 // :133 (NaN falls through, as upstream)
-    pair_force_from_difference<MODE>(difference, e, vel_i, acc, tab);
+    pair_force_from_difference<MODE>(difference, e, vel_i, neighbour_vl<MODE>(vel_i), acc, tab);
 }
 
 // util.rs:92-103

@@ -4,8 +4,9 @@
 // pedoni-simulator/src/models/sfm.rs:58-88) and ::update_states (sfm.rs:91-255).
 //
 // Data layout in HBM (structure of arrays, all fp32 / u32):
-//   pos[2][cap] float2, vel[2][cap] float2      ping-pong twice per tick (sort, integrate)
-//   desired_speed[2][cap] f32, destination[2][cap] u32   ping-pong once per tick (sort)
+//   pos[2][cap] float2, velx[2][cap] float4 {vx, vy, vl, desired_speed}   ping-pong twice per
+//   tick (sort, integrate); vl = |v| * 0.1 of sfm.rs:144, filled in by the sort pass (neighbour_vl)
+//   destination[2][cap] u32   ping-pong once per tick (sort)
 //   key[cap] u32 (next cell id or DEAD), slots[cap] u32 (general-form scratch)
 //   skey[2][cap] u32 packed (cy << 16 | cx) cell of each sorted agent (unfused K_KEY only)
 //   cell_count[cells+1], cell_start[2][cells+1] u32 (= the reference's neighbor_grid_indices;
@@ -331,20 +332,27 @@ scan_rows_kernel(uint32_t* __restrict__ cell_count, const uint32_t* __restrict__
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64];
     const int32_t row = row0 + (int32_t)blockIdx.x;
+    uint32_t* in = cell_count + (size_t)row * (size_t)cols;
+    uint32_t* o = out + (size_t)row * (size_t)cols;
+    // the first chunk of the row's cells is fetched together with the row totals (two
+    // independent round trips instead of two dependent ones)
+    uint32_t v[4];
+    {
+        const int32_t first = (int32_t)threadIdx.x * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = first + k < cols ? in[first + k] : 0u;
+    }
     uint32_t part = 0;
     for (int32_t r = row0 + (int32_t)threadIdx.x; r < row; r += SCAN_THREADS) part += row_count[r];
     uint32_t before;
     block_exclusive_scan(part, lds, before);
     uint32_t carry = base + before;
-    uint32_t* in = cell_count + (size_t)row * (size_t)cols;
-    uint32_t* o = out + (size_t)row * (size_t)cols;
     for (int32_t c0 = 0; c0 < cols; c0 += SCAN_THREADS * 4) {
         const int32_t first = c0 + (int32_t)threadIdx.x * 4;
-        uint32_t v[4];
         uint32_t s = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            v[k] = first + k < cols ? in[first + k] : 0u;
+            if (c0 > 0) v[k] = first + k < cols ? in[first + k] : 0u;
             s += v[k];
         }
         uint32_t total;
@@ -371,16 +379,20 @@ scan_rows_kernel(uint32_t* __restrict__ cell_count, const uint32_t* __restrict__
 
 // ---- K_PLACE (PEDONI_K_SLOT): rank inside the cell + move ------------------------------------
 struct SoA {
-    const float2* pos_in; const float2* vel_in; const float* v0_in; const uint32_t* dest_in;
-    float2* pos_out; float2* vel_out; float* v0_out; uint32_t* dest_out;
+    const float2* pos_in; const float4* velx_in; const uint32_t* dest_in;
+    float2* pos_out; float4* velx_out; uint32_t* dest_out;
     uint32_t* skey_out;
+    int32_t fast;   // PEDONI_MATH_FAST: which form of vl the force kernel expects
 };
 
+// moves one agent to its sorted place and fills in its |v| * 0.1 for the pairs in which it
+// will be the neighbour (device_math.hpp neighbour_vl)
 __device__ __forceinline__ void move_agent(const SoA& a, uint32_t from, uint32_t to, uint32_t packed)
 {
     a.pos_out[to] = a.pos_in[from];
-    a.vel_out[to] = a.vel_in[from];
-    a.v0_out[to] = a.v0_in[from];
+    float4 v = a.velx_in[from];
+    v.z = a.fast ? neighbour_vl<1>(mk(v.x, v.y)) : neighbour_vl<0>(mk(v.x, v.y));
+    a.velx_out[to] = v;
     a.dest_out[to] = a.dest_in[from];
     a.skey_out[to] = packed;
 }
@@ -481,28 +493,25 @@ __global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, ui
 // no-grid compaction: survivor i goes to its exclusive flag prefix
 __global__ void compact_kernel(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ prefix,
                                uint32_t n_total, const float2* __restrict__ pos_in,
-                               const float2* __restrict__ vel_in, const float* __restrict__ v0_in,
-                               const uint32_t* __restrict__ dest_in, float2* __restrict__ pos_out,
-                               float2* __restrict__ vel_out, float* __restrict__ v0_out,
+                               const float4* __restrict__ velx_in, const uint32_t* __restrict__ dest_in,
+                               float2* __restrict__ pos_out, float4* __restrict__ velx_out,
                                uint32_t* __restrict__ dest_out)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total || !flag[i]) return;
     uint32_t p = prefix[i];
     pos_out[p] = pos_in[i];
-    vel_out[p] = vel_in[i];
-    v0_out[p] = v0_in[i];
+    velx_out[p] = velx_in[i];      // (the brute-force kernel computes |v| * 0.1 itself)
     dest_out[p] = dest_in[i];
 }
 
 // ---- K_FORCE -------------------------------------------------------------------------
 struct ForceArgs {
     const float2* pos;   // sorted state (read)
-    const float2* vel;
-    const float* v0;
+    const float4* velx;  // {vx, vy, |v| * 0.1 (neighbour_vl), desired speed}
     const uint32_t* dest;
     float2* pos_out;     // integrated state (write); may be null for acc-only
-    float2* vel_out;
+    float4* velx_out;
     float2* acc_out;     // optional: accelerations only (no integration)
     const uint32_t* live_count; // absolute end index of the sorted agents
     uint32_t base;              // absolute index of the first sorted agent
@@ -596,9 +605,10 @@ __global__ void force_kernel_simple(ForceArgs a)
     uint32_t n = *a.live_count;
     if (id >= n) return;
 
-    float2 p = a.pos[id], vv = a.vel[id];
+    float2 p = a.pos[id];
+    float4 vv = a.velx[id];
     v2 pos = mk(p.x, p.y), vel = mk(vv.x, vv.y);
-    float desired_speed = a.v0[id];
+    float desired_speed = vv.w;
     uint32_t destination = a.dest[id];
 
     int32_t ix = 0, iy = 0;
@@ -609,7 +619,7 @@ __global__ void force_kernel_simple(ForceArgs a)
             if (a.pos_out) {                                 // NaN position = "not mine"; the
                 float qn = __builtin_nanf("");               // next sort/despawn pass drops it
                 a.pos_out[id] = make_float2(qn, qn);
-                a.vel_out[id] = vv;
+                a.velx_out[id] = vv;
             }
             return;
         }
@@ -628,7 +638,8 @@ __global__ void force_kernel_simple(ForceArgs a)
             uint32_t i_end = a.cell_start[offset + x_end + 1];
             for (uint32_t i = i_start; i < i_end; ++i) {
                 if (i != id) {
-                    float2 pi = a.pos[i], vi = a.vel[i];
+                    float2 pi = a.pos[i];
+                    float4 vi = a.velx[i];
                     pair_force<MODE>(pos, e, mk(pi.x, pi.y), mk(vi.x, vi.y), acc, tab);
                 }
             }
@@ -636,7 +647,8 @@ __global__ void force_kernel_simple(ForceArgs a)
     } else {                                                 // :157-185
         for (uint32_t i = a.base; i < n; ++i) {
             if (i != id) {
-                float2 pi = a.pos[i], vi = a.vel[i];
+                float2 pi = a.pos[i];
+                float4 vi = a.velx[i];
                 pair_force<MODE>(pos, e, mk(pi.x, pi.y), mk(vi.x, vi.y), acc, tab);
             }
         }
@@ -658,7 +670,7 @@ __global__ void force_kernel_simple(ForceArgs a)
     }
     pos = pos + (vel + vel_prev) * 0.05f;
     a.pos_out[id] = make_float2(pos.x, pos.y);
-    a.vel_out[id] = make_float2(vel.x, vel.y);
+    a.velx_out[id] = make_float4(vel.x, vel.y, 0.0f, desired_speed);   // (vl: filled by the next sort pass)
 }
 
 // ---- K_FORCE, wave-queue form (grid path) ----------------------------------------------
@@ -666,12 +678,13 @@ __global__ void force_kernel_simple(ForceArgs a)
 // the expensive pair evaluation is decoupled from ownership:
 //   phase 1  every lane walks its own candidate list (3 contiguous index ranges, rows
 //            y-1..y+1) SLOTS candidates at a time and does only the cutoff test
-//            (|d|^2 > 4 -> skip, sfm.rs:133).  Survivors are compacted with
-//            ballot + mbcnt into a per-wave queue in LDS: {dx, dy, neighbour velocity} and
-//            the owner lane.
-//   phase 2  the queue is drained 64 entries at a time: every lane evaluates one pair
-//            force (3 sqrt, 6 div, 1 exp: the hot 95 %) with no divergence and
-//            overwrites its queue entry with the result.
+//            (|d|^2 > 4 -> skip, sfm.rs:133), on positions only.  Survivors are compacted
+//            with ballot + mbcnt into a per-wave queue in LDS: {dx, dy} and one word holding
+//            the neighbour's index (26 bits) and the owner lane (6 bits): 12 bytes an entry.
+//   phase 2  the queue is drained 64 entries at a time: every lane fetches its neighbour's
+//            {vx, vy, |v| * 0.1} (one 16-byte load, issued first; the distance / direction
+//            arithmetic that does not need it runs underneath), evaluates one pair force (4
+//            sqrt, 6 div, 1 exp) with no divergence and overwrites {dx, dy} with the result.
 //   phase 3  each owner adds its results in candidate order -- rows ascending, index
 //            ascending, exactly the reference's `acc += force` sequence -- so the sum is
 //            bit-identical to the serial loop although pairs were evaluated in parallel.
@@ -692,14 +705,14 @@ template <int MODE, int SLOTS>
 __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
 {
     __shared__ uint64_t tab[32];
-    __shared__ float4 queue_all[FORCE_WAVES][SLOTS * 64];
-    __shared__ unsigned char owner_all[FORCE_WAVES][SLOTS * 64];
+    __shared__ float2 queue_all[FORCE_WAVES][SLOTS * 64];    // {dx, dy} in, {fx, fy} out
+    __shared__ uint32_t who_all[FORCE_WAVES][SLOTS * 64];    // neighbour index | owner lane << 26
     if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    float4* queue = queue_all[wave];
-    unsigned char* owner_of = owner_all[wave];
+    float2* queue = queue_all[wave];
+    uint32_t* who = who_all[wave];
     const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
     uint32_t id = a.base + block * blockDim.x + threadIdx.x;
     uint32_t n = *a.live_count;
@@ -723,17 +736,17 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
     bool valid = id < n;
 
     v2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), acc = mk(0.0f, 0.0f), e = mk(0.0f, 0.0f);
-    float2 vv = make_float2(0.0f, 0.0f);
+    float4 vv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float desired_speed = 0.0f;
     uint32_t r0 = 0, r1 = 0, r2 = 0, n0 = 0, n1 = 0, n2 = 0;
     bool ghost = false;
     int32_t ix = 0, iy = 0;   // the agent's cell (kept for the far-mover test of the tail)
     if (valid) {
         float2 p = a.pos[id];
-        vv = a.vel[id];
+        vv = a.velx[id];
         pos = mk(p.x, p.y);
         vel = mk(vv.x, vv.y);
-        desired_speed = a.v0[id];
+        desired_speed = vv.w;
         uint32_t destination = a.dest[id];
         ix = f32_as_i32(pos.x / a.grid.unit);                    // sfm.rs:113
         iy = f32_as_i32(pos.y / a.grid.unit);
@@ -772,16 +785,16 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         // three unrolled sub-passes so that the SLOTS position loads, then the SLOTS
         // velocity loads, are all in flight together
         uint32_t qlen = 0;       // wave-uniform
-        uint32_t passmask = 0;
-        uint32_t slot_of[SLOTS];
+        uint32_t slot_of[SLOTS]; // queue slot of candidate k, or ~0 when it did not pass
         uint32_t idx[SLOTS];
-        float2 d[SLOTS], vi[SLOTS];
+        float2 d[SLOTS];
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
             uint32_t s = base + k;
             uint32_t i = s + (s < n0 ? r0 : (s < n01 ? r1s : r2s));
             idx[k] = s < cnt ? i : id_safe;
-            d[k] = a.pos[idx[k]];
+            // (indices are < 2^26: a 32-bit byte offset beside the uniform base address)
+            d[k] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.pos) + (idx[k] << 3));
         }
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
@@ -789,40 +802,40 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
             float dy = pos.y - d[k].y;
             float d2 = (dx * dx) + (dy * dy);                     // :132
             // :130,133 (idx == id also marks "no candidate in this slot")
-            bool pass = !(d2 > 4.0f) && idx[k] != id_safe;
-            d[k] = make_float2(dx, dy);
-            vi[k] = a.vel[pass ? idx[k] : id_safe];               // :140
-            passmask |= pass ? 1u << k : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            bool pass = (passmask >> k) & 1u;
-            unsigned long long mask = __ballot(pass);
-            uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                  __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            uint32_t slot = qlen + before;
-            slot_of[k] = slot;
+            // (two ballots of plain compares: hipcc re-materialises a ballot of their conjunction
+            // through a VGPR, two VALU instructions per slot)
+            const bool near = !(d2 > 4.0f), other = idx[k] != id_safe;
+            const bool pass = near && other;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(near) & __builtin_amdgcn_ballot_w64(other);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const uint32_t slot = qlen + before;
+            slot_of[k] = pass ? slot : 0xffffffffu;
             if (pass) {
-                queue[slot] = make_float4(d[k].x, d[k].y, vi[k].x, vi[k].y);
-                owner_of[slot] = (unsigned char)lane;
+                queue[slot] = make_float2(dx, dy);
+                who[slot] = idx[k] | (lane << 26);
             }
             qlen += (uint32_t)__popcll(mask);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // ---- phase 2: one pair force per lane, no divergence, no global memory ----------
+        // ---- phase 2: one pair force per lane, no divergence ------------------------------
         for (uint32_t q0 = 0; q0 < qlen; q0 += 64) {
             uint32_t q = q0 + lane;
             const bool busy = q < qlen;
+            const uint32_t w = busy ? who[q] : (id_safe | (lane << 26));
+            // the neighbour's velocity and |v| * 0.1 (sfm.rs:140,144): one 16-byte load
+            const float4 vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.velx) +
+                                                               ((w & 0x03ffffffu) << 4));
             // the owner's goal direction, straight from its registers (every lane takes part)
-            const int own = busy ? (int)owner_of[q] : (int)lane;
+            const int own = (int)(w >> 26);
             const float eo_x = __shfl(e.x, own, 64), eo_y = __shfl(e.y, own, 64);
             if (busy) {
-                float4 en = queue[q];
+                float2 en = queue[q];
                 v2 f = mk(0.0f, 0.0f);
-                pair_force_from_difference<MODE>(mk(en.x, en.y), mk(eo_x, eo_y), mk(en.z, en.w), f, tab);
-                reinterpret_cast<float2*>(&queue[q])[0] = make_float2(f.x, f.y);
+                pair_force_from_difference<MODE>(mk(en.x, en.y), mk(eo_x, eo_y), mk(vn.x, vn.y), vn.z, f, tab);
+                queue[q] = make_float2(f.x, f.y);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -831,8 +844,8 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         // ---- phase 3: ordered accumulation (sfm.rs:153) ---------------------------------
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
-            if (passmask & (1u << k)) {
-                float2 f = reinterpret_cast<const float2*>(&queue[slot_of[k]])[0];
+            if (slot_of[k] != 0xffffffffu) {
+                float2 f = queue[slot_of[k]];
                 acc = acc + mk(f.x, f.y);
             }
         }
@@ -849,7 +862,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         if (a.pos_out) {                                          // NaN position = "not mine"; the
             float qn = __builtin_nanf("");                        // next sort/despawn pass drops it
             a.pos_out[id] = make_float2(qn, qn);
-            a.vel_out[id] = vv;
+            a.velx_out[id] = vv;
             if (a.key_next) a.key_next[id] = DEAD;
         }
         return;
@@ -872,7 +885,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
     }
     pos = pos + (vel + vel_prev) * 0.05f;
     a.pos_out[id] = make_float2(pos.x, pos.y);
-    a.vel_out[id] = make_float2(vel.x, vel.y);
+    a.velx_out[id] = make_float4(vel.x, vel.y, 0.0f, desired_speed);   // (vl: filled by the next sort pass)
 
     // fused K_KEY for the next tick: same arithmetic as key_kernel on the new position (the
     // potential texels are the ones the goal stencil just touched, so they come from L1/L2)
@@ -902,7 +915,7 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
 // default and 7 at <= 96 -- the 7th wave per SIMD that the <= 72 VGPRs and a 5-slot queue
 // (22 KB LDS per block) already allow.
 template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS) __attribute__((amdgpu_num_sgpr(94)))
+__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
 force_kernel_queue_s94(ForceArgs a)
 {
     force_queue_body<MODE, SLOTS>(a);
@@ -933,8 +946,8 @@ __device__ __forceinline__ double wyrand_f64(unsigned long long& s) { return (do
 
 __global__ void spawn_kernel(const SpawnerDev* __restrict__ sp, uint32_t n_sp, SpawnState* __restrict__ st,
                              uint32_t at0, uint32_t cap, float2* __restrict__ pos,
-                             float2* __restrict__ vel, float* __restrict__ v0,
-                             uint32_t* __restrict__ dest, HaloIn* __restrict__ halo)
+                             float4* __restrict__ velx, uint32_t* __restrict__ dest,
+                             HaloIn* __restrict__ halo)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     unsigned long long rp = st->rng_pos, rv = st->rng_v0;
@@ -952,7 +965,6 @@ __global__ void spawn_kernel(const SpawnerDev* __restrict__ sp, uint32_t n_sp, S
             float2 p = make_float2(sp[k].x0 * w + sp[k].x1 * u, sp[k].y0 * w + sp[k].y1 * u);
             if (n < cap) {
                 pos[at0 + n] = p;
-                vel[at0 + n] = make_float2(0.0f, 0.0f);       // sfm.rs:53
                 dest[at0 + n] = sp[k].destination;
                 n += 1;
             } else {
@@ -963,7 +975,7 @@ __global__ void spawn_kernel(const SpawnerDev* __restrict__ sp, uint32_t n_sp, S
     for (uint32_t i = 0; i < n + dropped; ++i) {              // sfm.rs:54, one draw per agent
         float acc = 0.0f;
         for (int j = 0; j < 12; ++j) acc += wyrand_f32(rv);
-        if (i < n) v0[at0 + i] = 1.34f + 0.26f * (acc - 6.0f);
+        if (i < n) velx[at0 + i] = make_float4(0.0f, 0.0f, 0.0f, 1.34f + 0.26f * (acc - 6.0f)); // sfm.rs:53-54
     }
     st->rng_pos = rp;
     st->rng_v0 = rv;
@@ -984,9 +996,8 @@ struct HaloList {            // device layout of one direction's buffer
 };
 
 __global__ void __launch_bounds__(1024)
-halo_pack_kernel(const float2* __restrict__ pos, const float2* __restrict__ vel,
-                 const float* __restrict__ v0, const uint32_t* __restrict__ dest,
-                 const uint32_t* __restrict__ cs, GridView grid, int32_t band_lo, int32_t band_hi,
+halo_pack_kernel(const float2* __restrict__ pos, const float4* __restrict__ velx,
+                 const uint32_t* __restrict__ dest, const uint32_t* __restrict__ cs, GridView grid, int32_t band_lo, int32_t band_hi,
                  uint32_t cap_each, uint32_t* __restrict__ send)
 {
     __shared__ uint32_t lds[16];
@@ -1019,10 +1030,10 @@ halo_pack_kernel(const float2* __restrict__ pos, const float2* __restrict__ vel,
         if (take) {
             if (at < cap_each) {
                 uint32_t* r = rec + (size_t)at * PEDONI_HALO_RECORD_WORDS;
-                float2 v = vel[i];
+                float4 v = velx[i];
                 r[0] = __float_as_uint(p.x); r[1] = __float_as_uint(p.y);
                 r[2] = __float_as_uint(v.x); r[3] = __float_as_uint(v.y);
-                r[4] = __float_as_uint(v0[i]); r[5] = dest[i];
+                r[4] = __float_as_uint(v.w); r[5] = dest[i];
             } else {
                 flags |= 1u;                              // list overflow
             }
@@ -1048,8 +1059,7 @@ halo_pack_kernel(const float2* __restrict__ pos, const float2* __restrict__ vel,
 __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
                                    const uint32_t* __restrict__ from_above, uint32_t cap_each,
                                    uint32_t n_behind, uint32_t base, uint32_t gap_end,
-                                   float2* __restrict__ pos,
-                                   float2* __restrict__ vel, float* __restrict__ v0,
+                                   float2* __restrict__ pos, float4* __restrict__ velx,
                                    uint32_t* __restrict__ dest, HaloIn* __restrict__ halo,
                                    FieldView field, GridView grid, int32_t band_lo, int32_t band_hi,
                                    uint32_t parity, SortFlags* __restrict__ flags,
@@ -1091,8 +1101,7 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
         v2 p = mk(__uint_as_float(src[0]), __uint_as_float(src[1]));
         uint32_t d = src[5];
         pos[at] = make_float2(p.x, p.y);
-        vel[at] = make_float2(__uint_as_float(src[2]), __uint_as_float(src[3]));
-        v0[at] = __uint_as_float(src[4]);
+        velx[at] = make_float4(__uint_as_float(src[2]), __uint_as_float(src[3]), 0.0f, __uint_as_float(src[4]));
         dest[at] = d;
         if (cell_xy(grid, p, cx, cy) && cy >= band_lo - 1 && cy <= band_hi && survives(field, p, d)) {
             {

@@ -100,11 +100,10 @@ struct PedoniModel {
     // agents
     uint32_t cap = 0;
     float2* d_pos[2] = {nullptr, nullptr};
-    float2* d_vel[2] = {nullptr, nullptr};
-    float* d_v0[2] = {nullptr, nullptr};
+    float4* d_velx[2] = {nullptr, nullptr}; // {vx, vy, |v| * 0.1 (filled by the sort pass), desired speed}
     uint32_t* d_dest[2] = {nullptr, nullptr};
-    int pv = 0; // buffer holding current pos/vel
-    int vd = 0; // buffer holding current desired_speed/destination
+    int pv = 0; // buffer holding current pos / velx
+    int vd = 0; // buffer holding current destination
     uint32_t* d_key = nullptr;
     uint32_t* d_slots = nullptr;
     uint32_t* d_scan_in = nullptr;  // cell_count (grid) or flags (no grid)
@@ -236,7 +235,8 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
     if (need <= m->cap) return PEDONI_OK;
     uint64_t nc = std::max<uint64_t>(m->cap ? m->cap : 1024, 1024);
     while (nc < need) nc *= 2;
-    if (nc > 0xfffffff0ull) return fail(PEDONI_E_INVALID, "agent capacity exceeds 2^32");
+    // (the force kernel's pair queue packs a neighbour index into 26 bits beside the owner lane)
+    if (nc > (1ull << 26)) return fail(PEDONI_E_INVALID, "agent capacity exceeds 2^26 (67 M) agents per GPU");
     const uint32_t ncap = (uint32_t)nc;
     const bool per_agent_scan = !m->opt.use_neighbor_grid; // the scan runs over per-agent flags
     const uint32_t nscan = ncap + 1, nsums = (nscan + SCAN_TILE - 1) / SCAN_TILE + 1;
@@ -247,15 +247,14 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
         if (rc == PEDONI_OK) fresh.push_back((void*)*p);
         return rc;
     };
-    float2 *npos[2] = {nullptr, nullptr}, *nvel[2] = {nullptr, nullptr};
-    float* nv0[2] = {nullptr, nullptr};
+    float2* npos[2] = {nullptr, nullptr};
+    float4* nvel[2] = {nullptr, nullptr};
     uint32_t *ndest[2] = {nullptr, nullptr}, *nskey[2] = {nullptr, nullptr};
     uint32_t *nkey = nullptr, *nslots = nullptr, *nscan_in = nullptr, *ncs0 = nullptr, *nblock_sums = nullptr;
     int rc = PEDONI_OK;
     for (int k = 0; k < 2 && rc == PEDONI_OK; ++k) {
         rc = grab(&npos[k], ncap);
         if (rc == PEDONI_OK) rc = grab(&nvel[k], ncap);
-        if (rc == PEDONI_OK) rc = grab(&nv0[k], ncap);
         if (rc == PEDONI_OK) rc = grab(&ndest[k], ncap);
         if (rc == PEDONI_OK) rc = grab(&nskey[k], ncap);
     }
@@ -270,8 +269,7 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
         if (!m->n_upper) return PEDONI_OK;
         const size_t n = m->n_upper;
         HIP_TRY(hipMemcpyAsync(npos[m->pv], m->d_pos[m->pv], n * sizeof(float2), hipMemcpyDeviceToDevice, m->stream));
-        HIP_TRY(hipMemcpyAsync(nvel[m->pv], m->d_vel[m->pv], n * sizeof(float2), hipMemcpyDeviceToDevice, m->stream));
-        HIP_TRY(hipMemcpyAsync(nv0[m->vd], m->d_v0[m->vd], n * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(nvel[m->pv], m->d_velx[m->pv], n * sizeof(float4), hipMemcpyDeviceToDevice, m->stream));
         HIP_TRY(hipMemcpyAsync(ndest[m->vd], m->d_dest[m->vd], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
         return PEDONI_OK;
@@ -283,9 +281,9 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
     }
     HIP_TRY(hipStreamSynchronize(m->stream)); // nothing in flight still reads the old arrays
     for (int k = 0; k < 2; ++k) {
-        hipFree(m->d_pos[k]); hipFree(m->d_vel[k]); hipFree(m->d_v0[k]); hipFree(m->d_dest[k]);
+        hipFree(m->d_pos[k]); hipFree(m->d_velx[k]); hipFree(m->d_dest[k]);
         hipFree(m->d_skey[k]);
-        m->d_pos[k] = npos[k]; m->d_vel[k] = nvel[k]; m->d_v0[k] = nv0[k]; m->d_dest[k] = ndest[k];
+        m->d_pos[k] = npos[k]; m->d_velx[k] = nvel[k]; m->d_dest[k] = ndest[k];
         m->d_skey[k] = nskey[k];
     }
     hipFree(m->d_key); hipFree(m->d_slots);
@@ -365,8 +363,9 @@ int sort_despawn(PedoniModel* m)
         const BandView band{m->band_lo, m->band_hi, m->halo_cap ? 1 : 0};
         // a band only ever touches the cells of rows lo-1 .. hi: scan just those
         const int32_t row0 = std::max(m->band_lo - 1, 0), row1 = std::min(m->band_hi + 1, m->grid.rows);
-        SoA soa{m->d_pos[src], m->d_vel[src], m->d_v0[vsrc], m->d_dest[vsrc],
-                m->d_pos[dst], m->d_vel[dst], m->d_v0[vdst], m->d_dest[vdst], m->d_skey[sk_new]};
+        SoA soa{m->d_pos[src], m->d_velx[src], m->d_dest[vsrc],
+                m->d_pos[dst], m->d_velx[dst], m->d_dest[vdst], m->d_skey[sk_new],
+                m->opt.math_mode == PEDONI_MATH_FAST ? 1 : 0};
         {
             Timed t(m, PEDONI_K_BIN);
             if (t.rc) return t.rc;
@@ -442,8 +441,8 @@ int sort_despawn(PedoniModel* m)
             if (t.rc) return t.rc;
             hipLaunchKernelGGL(compact_kernel, dim3(blocks_for(n_total, bs)), dim3(bs), 0,
                                m->stream, m->d_key, m->d_cs[0], n_total, m->d_pos[src],
-                               m->d_vel[src], m->d_v0[vsrc], m->d_dest[vsrc], m->d_pos[dst],
-                               m->d_vel[dst], m->d_v0[vdst], m->d_dest[vdst]);
+                               m->d_velx[src], m->d_dest[vsrc], m->d_pos[dst], m->d_velx[dst],
+                               m->d_dest[vdst]);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -459,11 +458,10 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
 {
     ForceArgs a{};
     a.pos = m->d_pos[m->pv];
-    a.vel = m->d_vel[m->pv];
-    a.v0 = m->d_v0[m->vd];
+    a.velx = m->d_velx[m->pv];
     a.dest = m->d_dest[m->vd];
     a.pos_out = acc_out ? nullptr : m->d_pos[1 - m->pv];
-    a.vel_out = acc_out ? nullptr : m->d_vel[1 - m->pv];
+    a.velx_out = acc_out ? nullptr : m->d_velx[1 - m->pv];
     a.acc_out = acc_out;
     a.live_count = m->d_live;
     a.base = m->base;
@@ -523,17 +521,20 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
     const bool fast = m->opt.math_mode == PEDONI_MATH_FAST;
     if (m->opt.use_neighbor_grid && !m->force_simple) {
         dim3 grid(blocks_for(n, FORCE_THREADS)), block(FORCE_THREADS);
-        // candidate slots per lane and batch: 6 slots = 26 KB LDS per block = 6 workgroups per
-        // CU; 5 slots = 22 KB, which with the 94-SGPR build of the kernel lets a CU admit a 7th
-        // workgroup (7 waves/SIMD at 70 VGPRs).  Measured at N = 1e6, exact mode: 103.7 us with
-        // 5 slots / 7 waves against 106.6 us with 6 / 6; the fast mode and small crowds (whose
-        // waves are few anyway) do not gain, so they keep 6 slots -- fewer batches per wave.
+        // 6 candidate slots per lane and batch (12-byte queue entries: 18 KB LDS per block).  For
+        // large crowds the 94-SGPR, 7-waves-per-SIMD build of the kernel (kernels.hpp
+        // force_kernel_queue_s94): 96.2 us against 100.5 us at N = 1e6, exact mode; small crowds
+        // (few waves per SIMD anyway) keep the default build.  PEDONI_FORCE_SLOTS overrides:
+        // 4 / 5 (s94), 6, 8, 15 (5 slots, default SGPRs), 16 / 18 (s94 with 6 / 8 slots).
         int slots = m->force_slots;
-        if (slots == 0) slots = (!fast && n >= 400000u) ? 5 : 6;
+        if (slots == 0) slots = n >= 400000u ? 16 : 6;
         switch (slots + (fast ? 100 : 0)) {
         case 4: hipLaunchKernelGGL((force_kernel_queue_s94<0, 4>), grid, block, 0, stream, a); break;
         case 5: hipLaunchKernelGGL((force_kernel_queue_s94<0, 5>), grid, block, 0, stream, a); break;
         case 15: hipLaunchKernelGGL((force_kernel_queue<0, 5>), grid, block, 0, stream, a); break;
+        case 16: hipLaunchKernelGGL((force_kernel_queue_s94<0, 6>), grid, block, 0, stream, a); break;
+        case 18: hipLaunchKernelGGL((force_kernel_queue_s94<0, 8>), grid, block, 0, stream, a); break;
+        case 116: hipLaunchKernelGGL((force_kernel_queue_s94<1, 6>), grid, block, 0, stream, a); break;
         case 8: hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, stream, a); break;
         case 104: hipLaunchKernelGGL((force_kernel_queue_s94<1, 4>), grid, block, 0, stream, a); break;
         case 105: hipLaunchKernelGGL((force_kernel_queue_s94<1, 5>), grid, block, 0, stream, a); break;
@@ -636,17 +637,16 @@ int append(PedoniModel* m, const float* pos_xy, const uint32_t* destination,
     size_t at = m->n_upper;
     HIP_TRY(hipMemcpyAsync(m->d_pos[m->pv] + at, pos_xy, n * sizeof(float2), hipMemcpyHostToDevice,
                            m->stream));
-    if (vel_xy)
-        HIP_TRY(hipMemcpyAsync(m->d_vel[m->pv] + at, vel_xy, n * sizeof(float2),
-                               hipMemcpyHostToDevice, m->stream));
-    else
-        HIP_TRY(hipMemsetAsync(m->d_vel[m->pv] + at, 0, n * sizeof(float2), m->stream)); // :53
-    HIP_TRY(hipMemcpyAsync(m->d_v0[m->vd] + at, v0.data(), n * sizeof(float), hipMemcpyHostToDevice,
+    // {vx, vy, (|v| * 0.1: filled by the sort pass), desired speed}; velocity 0 when not given (:53)
+    std::vector<float4> velx(n);
+    for (uint32_t i = 0; i < n; ++i)
+        velx[i] = make_float4(vel_xy ? vel_xy[2 * i] : 0.0f, vel_xy ? vel_xy[2 * i + 1] : 0.0f, 0.0f, v0[i]);
+    HIP_TRY(hipMemcpyAsync(m->d_velx[m->pv] + at, velx.data(), n * sizeof(float4), hipMemcpyHostToDevice,
                            m->stream));
     HIP_TRY(hipMemcpyAsync(m->d_dest[m->vd] + at, destination, n * sizeof(uint32_t),
                            hipMemcpyHostToDevice, m->stream));
     // pageable host buffers: the copies above are staged synchronously by the runtime, but
-    // v0 is a local -- make sure it has been consumed before it goes out of scope
+    // velx is a local -- make sure it has been consumed before it goes out of scope
     HIP_TRY(hipStreamSynchronize(m->stream));
     m->n_upper += n;
     m->sorted = false;
@@ -842,7 +842,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     if (m->stream) hipStreamSynchronize(m->stream);
     for (auto& p : m->ev_pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (int k = 0; k < 2; ++k) {
-        hipFree(m->d_pos[k]); hipFree(m->d_vel[k]); hipFree(m->d_v0[k]); hipFree(m->d_dest[k]);
+        hipFree(m->d_pos[k]); hipFree(m->d_velx[k]); hipFree(m->d_dest[k]);
     }
     hipFree(m->d_key); hipFree(m->d_slots);
     hipFree(m->d_scan_in); hipFree(m->d_cs[0]); hipFree(m->d_cs[1]); hipFree(m->d_block_sums);
@@ -917,8 +917,8 @@ int device_spawn(PedoniModel* m)
     Timed t(m, PEDONI_K_OTHER);
     if (t.rc) return t.rc;
     hipLaunchKernelGGL(spawn_kernel, dim3(1), dim3(64), 0, m->stream, m->d_spawners, m->n_spawners,
-                       m->d_spawn_state, m->n_upper, m->spawn_cap, m->d_pos[m->pv], m->d_vel[m->pv],
-                       m->d_v0[m->vd], m->d_dest[m->vd], m->d_halo);
+                       m->d_spawn_state, m->n_upper, m->spawn_cap, m->d_pos[m->pv], m->d_velx[m->pv],
+                       m->d_dest[m->vd], m->d_halo);
     HIP_TRY(hipGetLastError());
     m->gap_end = m->n_upper;        // the spawned agents start here
     m->n_upper += m->spawn_cap;     // host bound; the device knows the true count
@@ -1143,10 +1143,17 @@ int pedoni_hip_download(PedoniModel* m, float* pos_xy, uint32_t* destination, fl
         return PEDONI_OK;
     };
     TRY(copy(pos_xy, m->d_pos[m->pv], sizeof(float2)));
-    TRY(copy(vel_xy, m->d_vel[m->pv], sizeof(float2)));
-    TRY(copy(desired_speed, m->d_v0[m->vd], sizeof(float)));
+    std::vector<float4> velx;
+    if (vel_xy || desired_speed) {
+        velx.resize((size_t)n1 + n2);
+        TRY(copy(velx.data(), m->d_velx[m->pv], sizeof(float4)));
+    }
     TRY(copy(destination, m->d_dest[m->vd], sizeof(uint32_t)));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    for (size_t i = 0; i < velx.size(); ++i) {          // {vx, vy, vl, desired speed} -> the two host arrays
+        if (vel_xy) { vel_xy[2 * i] = velx[i].x; vel_xy[2 * i + 1] = velx[i].y; }
+        if (desired_speed) desired_speed[i] = velx[i].w;
+    }
     return PEDONI_OK;
 }
 
@@ -1311,7 +1318,7 @@ int halo_pack_from(PedoniModel* m, void* send_dev, uint32_t cap_each, bool updat
     Timed t(m, PEDONI_K_HALO_PACK);
     if (t.rc) return t.rc;
     hipLaunchKernelGGL(halo_pack_kernel, dim3(2), dim3(1024), 0, m->stream, m->d_pos[src],
-                       m->d_vel[src], m->d_v0[m->vd], m->d_dest[m->vd], m->d_cs[m->cs], m->grid,
+                       m->d_velx[src], m->d_dest[m->vd], m->d_cs[m->cs], m->grid,
                        m->band_lo, m->band_hi, cap_each, (uint32_t*)send_dev);
     HIP_TRY(hipGetLastError());
     return PEDONI_OK;
@@ -1363,7 +1370,7 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
     if (t.rc) return t.rc;
     hipLaunchKernelGGL(halo_unpack_kernel, dim3(blocks_for(cap_each + grow, 256)), dim3(256), 0,
                        m->stream, below, above, cap_each, grow, m->base, m->n_upper, m->d_pos[m->pv],
-                       m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_halo, m->field, m->grid,
+                       m->d_velx[m->pv], m->d_dest[m->vd], m->d_halo, m->field, m->grid,
                        m->band_lo, m->band_hi, m->tick_parity & 1u, m->d_flags, m->d_key, m->d_scan_in,
                        m->d_row_count);
     HIP_TRY(hipGetLastError());

@@ -89,8 +89,8 @@ __global__ void row_hist_kernel(const uint32_t* __restrict__ cs, int32_t cols, i
 
 // whole rows [row_a, row_b) of the sorted order -- one contiguous index range -- as a record
 // list (same record as the halo lists); header {count, overflow flag, 0, 0}
-__global__ void bulk_pack_kernel(const float2* __restrict__ pos, const float2* __restrict__ vel,
-                                 const float* __restrict__ v0, const uint32_t* __restrict__ dest,
+__global__ void bulk_pack_kernel(const float2* __restrict__ pos, const float4* __restrict__ velx,
+                                 const uint32_t* __restrict__ dest,
                                  const uint32_t* __restrict__ cs, int32_t cols, int32_t row_a, int32_t row_b,
                                  uint32_t cap, uint32_t* __restrict__ out)
 {
@@ -106,17 +106,18 @@ __global__ void bulk_pack_kernel(const float2* __restrict__ pos, const float2* _
     if (t >= n || t >= cap) return;
     const uint32_t i = begin + t;
     uint32_t* r = out + PEDONI_HALO_HEADER_WORDS + (size_t)t * PEDONI_HALO_RECORD_WORDS;
-    const float2 p = pos[i], v = vel[i];
+    const float2 p = pos[i];
+    const float4 v = velx[i];
     r[0] = __float_as_uint(p.x); r[1] = __float_as_uint(p.y);
     r[2] = __float_as_uint(v.x); r[3] = __float_as_uint(v.y);
-    r[4] = __float_as_uint(v0[i]); r[5] = dest[i];
+    r[4] = __float_as_uint(v.w); r[5] = dest[i];
 }
 
 // appends both incoming lists behind everything stored: [at0, at0 + nA) then [.., + nB)
 __global__ void bulk_unpack_kernel(const uint32_t* __restrict__ in_a, const uint32_t* __restrict__ in_b,
                                    uint32_t cap, uint32_t at0, float2* __restrict__ pos,
-                                   float2* __restrict__ vel, float* __restrict__ v0,
-                                   uint32_t* __restrict__ dest, HaloIn* __restrict__ halo)
+                                   float4* __restrict__ velx, uint32_t* __restrict__ dest,
+                                   HaloIn* __restrict__ halo)
 {
     const uint32_t n_a = min(in_a[0], cap), n_b = min(in_b[0], cap);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -138,8 +139,7 @@ __global__ void bulk_unpack_kernel(const uint32_t* __restrict__ in_a, const uint
         at = at0 + n_a + k;
     }
     pos[at] = make_float2(__uint_as_float(src[0]), __uint_as_float(src[1]));
-    vel[at] = make_float2(__uint_as_float(src[2]), __uint_as_float(src[3]));
-    v0[at] = __uint_as_float(src[4]);
+    velx[at] = make_float4(__uint_as_float(src[2]), __uint_as_float(src[3]), 0.0f, __uint_as_float(src[4]));
     dest[at] = src[5];
 }
 
@@ -280,7 +280,7 @@ int recut_pack(PedoniShard* s, const std::vector<int32_t>& nb)
             if (dir == 0 && to > old) { row_a = old + 1; row_b = to + 1; }      // my bottom rows go down
         }
         hipLaunchKernelGGL(bulk_pack_kernel, dim3(blocks_for(s->bulk_cap, 256)), dim3(256), 0, m->stream,
-                           m->d_pos[m->pv], m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_cs[m->cs],
+                           m->d_pos[m->pv], m->d_velx[m->pv], m->d_dest[m->vd], m->d_cs[m->cs],
                            m->grid.cols, row_a, row_b, s->bulk_cap, s->d_bulk_send[dir]);
     }
     HIP_TRY(hipGetLastError());
@@ -330,7 +330,7 @@ int recut_apply(PedoniShard* s, const std::vector<int32_t>& nb)
     TRY(ensure_capacity(m, m->n_upper + 2 * s->bulk_cap));
     hipLaunchKernelGGL(bulk_unpack_kernel, dim3(blocks_for(2 * s->bulk_cap, 256)), dim3(256), 0, m->stream,
                        s->d_bulk_recv[0], s->d_bulk_recv[1], s->bulk_cap, m->n_upper, m->d_pos[m->pv],
-                       m->d_vel[m->pv], m->d_v0[m->vd], m->d_dest[m->vd], m->d_halo);
+                       m->d_velx[m->pv], m->d_dest[m->vd], m->d_halo);
     HIP_TRY(hipGetLastError());
     m->gap_end = m->n_upper;
     m->n_upper += 2 * s->bulk_cap;

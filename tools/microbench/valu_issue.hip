@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, in
         v2 acc = mk(0.0f, 0.0f);
         v2 diff = mk(0.3f + lane * 0.01f, 0.4f + lane * 0.005f), e = mk(0.8f, 0.6f), vi = mk(0.5f + lane * 0.001f, -0.3f);
         for (int i = 0; i < iters / 8; ++i) {
-            pair_force_from_difference<0>(diff, e, vi, acc, tab);
+            pair_force_from_difference<0>(diff, e, vi, neighbour_vl<0>(vi) + 0.0f * acc.x, acc, tab);
             diff.x = __uint_as_float(__float_as_uint(diff.x) ^ ((__float_as_uint(acc.x) >> 22) & 1u));   // keep it live, keep it in range
         }
         a0 = acc.x + acc.y;
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, in
         v2 acc = mk(0.0f, 0.0f);
         v2 diff = mk(0.3f + lane * 0.01f, 0.4f + lane * 0.005f), e = mk(0.8f, 0.6f), vi = mk(0.5f + lane * 0.001f, -0.3f);
         for (int i = 0; i < iters / 8; ++i) {
-            pair_force_from_difference<1>(diff, e, vi, acc, tab);
+            pair_force_from_difference<1>(diff, e, vi, neighbour_vl<1>(vi), acc, tab);
             diff.x = __uint_as_float(__float_as_uint(diff.x) ^ ((__float_as_uint(acc.x) >> 22) & 1u));
         }
         a0 = acc.x + acc.y;
