@@ -294,19 +294,39 @@ def main() -> None:
             # the driver below the C-ABI: libpedoni_hip owns an RCCL communicator and sends /
             # receives the lists itself (ncclSend / ncclRecv with rank +- 1 on the model's
             # stream).  torch.distributed only carries the 128-byte id and the timing barrier.
+            # (every rank takes part in every collective below whatever failed locally)
+            def agreed(ok: int) -> bool:
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return int(flag.item()) == 1
+
             ok, why = 1, ""
-            try:
-                idt = torch.zeros(abi.SHARD_ID_BYTES, dtype=torch.uint8, device="cuda")
-                if rank == 0:
+            idt = torch.zeros(abi.SHARD_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                try:
                     idt.copy_(torch.frombuffer(bytearray(abi.shard_unique_id()), dtype=torch.uint8))
-                dist.broadcast(idt, 0)
-                shard = abi.Shard(model, rank, G, bounds, cap, unique_id=bytes(idt.cpu().numpy().tobytes()))
-                shard.selftest()                   # a token ring through the very send / recv pair
-            except Exception as e:                 # noqa: BLE001 -- reported, then the fallback runs
-                ok, why = 0, str(e)
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
+                except Exception as e:             # noqa: BLE001 -- an all-zero id tells the others
+                    ok, why = 0, str(e)
+            dist.broadcast(idt, 0)
+            uid = bytes(idt.cpu().numpy().tobytes())
+            if not any(uid):
+                ok, why = 0, why or "rank 0 could not create an RCCL id"
+            if agreed(ok):
+                try:
+                    shard = abi.Shard(model, rank, G, bounds, cap, unique_id=uid)   # ncclCommInitRank
+                except Exception as e:             # noqa: BLE001
+                    ok, why = 0, str(e)
+                if agreed(ok):
+                    try:
+                        shard.selftest()           # a token ring through the very send / recv pair
+                    except Exception as e:         # noqa: BLE001
+                        ok, why = 0, str(e)
+                    ok = 1 if agreed(ok) else 0
+                else:
+                    ok = 0
+            else:
+                ok = 0
+            if ok == 1:
                 exchange = "direct RCCL ncclSend/ncclRecv to rank+-1, driven by libpedoni_hip (pedoni_shard_tick_n)"
             else:
                 print(f"[bench] rank {rank}: direct RCCL path unavailable ({why or 'another rank failed'}); "
@@ -459,6 +479,8 @@ def main() -> None:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
+    if shard is not None:
+        shard.close()                              # ncclCommDestroy before the model goes
     model.close()
     if dist is not None:
         dist.destroy_process_group()

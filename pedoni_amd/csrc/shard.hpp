@@ -351,9 +351,21 @@ bool recut_due(const PedoniShard* s)
 }
 
 // one tick of one rank over RCCL
+// with profiling on, only every profile_every-th tick is event-timed (as in pedoni_hip_tick_n)
+struct SampledProfile {
+    PedoniModel* m;
+    explicit SampledProfile(PedoniModel* m_) : m(m_)
+    {
+        m->profile_now = m->profile_mask != 0 && m->tick_counter % m->profile_every == 0;
+        m->tick_counter += 1;
+    }
+    ~SampledProfile() { m->profile_now = true; }
+};
+
 int shard_tick_rccl(PedoniShard* s)
 {
     PedoniModel* m = s->m;
+    SampledProfile sampled(m);
     TRY(shard_exchange_rccl(s));
     if (!recut_due(s)) {
         TRY(pedoni_hip_halo_tick(m, shard_below(s), shard_above(s), s->d_send, s->cap));
