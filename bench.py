@@ -143,7 +143,7 @@ def pmc_traffic(workload: str):
     (profiles/*pmc_force*.json written by tools/pmc_summary.py) for this workload, with the
     profile it came from -- (bytes, tag) or (None, None)."""
     best = (None, None)
-    for p in sorted((ROOT / "profiles").glob("*pmc_force*.json"), key=lambda q: q.stat().st_mtime):
+    for p in sorted((ROOT / "profiles").glob("*pmc_force*.json")):      # rNN_vM names sort by age
         try:
             d = json.loads(p.read_text())
         except Exception:
@@ -167,13 +167,15 @@ def valu_floor(avg_launch_ms: float):
     (GRBM_GUI_ACTIVE / 8 XCDs per launch / its SQ_BUSY time is not available, so the clock is
     cycles per launch / the profiled launch duration)."""
     best = None
-    for p in sorted((ROOT / "profiles").glob("*_stalls.json"), key=lambda q: q.stat().st_mtime):
+    names = sorted((ROOT / "profiles").glob("*_stalls.json"),
+                   key=lambda q: (0 if "_base_" in q.name else 1, q.name))                 # rNN_vM names sort by age
+    for p in names:
         try:
             d = json.loads(p.read_text())
         except Exception:
             continue
         for k, v in d.items():
-            if "force_kernel_queue<0" in k and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
+            if "force_kernel_queue" in k and "<0," in k and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
                 best = (v, p.name)
     if not best:
         return None

@@ -99,3 +99,31 @@ def test_c_abi_demo_runs_the_trait_calls(tmp_path):
     assert r.stdout.startswith("ticks=150 active=")
     active = int(r.stdout.split("active=")[1].split()[0])
     assert 0 <= active <= 20
+
+
+def _build_c_shard_demo(tmp_path):
+    exe = tmp_path / "c_shard_demo"
+    lib = ROOT / "pedoni_amd" / "lib"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", f"-I{ROOT / 'include'}",
+                    str(ROOT / "examples" / "c_shard_demo.c"), f"-L{lib}", "-lpedoni_host", "-lpedoni_hip", "-lm",
+                    f"-Wl,-rpath,{lib}", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_c_shard_demo_compiles_as_plain_c(tmp_path):
+    """The multi-GPU host example uses nothing but include/*.h from C11."""
+    _build_c_shard_demo(tmp_path)
+
+
+@pytest.mark.gpu
+def test_c_shard_demo_one_rank_rccl(tmp_path):
+    """One rank of the plain-C multi-GPU host: RCCL id through a file, communicator, token
+    self-test, band = the whole grid, agents walking to their goal (some arrive and despawn)."""
+    exe = _build_c_shard_demo(tmp_path)
+    r = subprocess.run([str(exe), str(SCENARIO), "0", "1", str(tmp_path / "id.bin"), "300"],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("rank=0/1 band=[0,15)")
+    before, after = (int(x) for x in r.stdout.split("owned ")[1].split(" -> "))
+    assert before > 100 and 0 <= after < before
+    assert (tmp_path / "id.bin").stat().st_size == 128
