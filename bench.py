@@ -360,6 +360,24 @@ def main() -> None:
         model.append(pos, dest, v0, vel)
         shard.begin()
         step_fn = shard.tick_n
+        # plain tick (exchange, then the whole update) or overlapped (the next exchange under the
+        # interior rows' update)?  Which is faster depends on what the exchange costs on this
+        # node: time 20 ticks of each, every rank keeps the mode that was faster for the slowest.
+        mode_ms = {}
+        for mode in (False, True):
+            shard.set_overlap(mode)
+            shard.tick_n(5)
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            shard.tick_n(20)
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mode_ms[mode] = float(t.item()) / 20 * 1e3
+        use_overlap = mode_ms[True] < mode_ms[False]
+        shard.set_overlap(use_overlap)
+        exchange += (f"; tick form: {'overlapped' if use_overlap else 'plain'} "
+                     f"(probe: plain {mode_ms[False] * 1e3:.0f} us, overlapped {mode_ms[True] * 1e3:.0f} us per tick)")
     elif runner is not None:
         assert (runner.owner_of(pos[:, 1]) == rank).all()
         runner.load(pos, dest, v0, vel)

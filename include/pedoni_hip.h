@@ -265,6 +265,11 @@ int pedoni_shard_begin(PedoniShard* s);
 int pedoni_shard_tick_n(PedoniShard* s, uint32_t steps);
 int pedoni_shard_owned_count(PedoniShard* s, int32_t* count);
 int pedoni_shard_band(PedoniShard* s, int32_t* row_begin, int32_t* row_end);
+/* on: the exchange of the NEXT tick's lists runs on a stream of its own while this tick's interior
+ * rows are still being computed (the tick is split: rows beside the band's edges, pack, send;
+ * then the interior).  Same results bit for bit; pays once the exchange costs more than the
+ * split does (two more launches, cross-stream waits) -- bench.py times both and keeps the faster. */
+int pedoni_shard_set_overlap(PedoniShard* s, int32_t on);
 /* a token ring through the very ncclSend / ncclRecv pair the exchange uses (self-addressed at
  * the outer bands): PEDONI_OK iff both neighbours' tokens arrived */
 int pedoni_shard_selftest(PedoniShard* s);

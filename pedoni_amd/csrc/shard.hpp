@@ -162,6 +162,12 @@ struct PedoniShard {
     uint32_t* h_hist = nullptr;       // pinned
     uint32_t* d_bulk_send[2] = {nullptr, nullptr}; // [0] for the band below, [1] for the band above
     uint32_t* d_bulk_recv[2] = {nullptr, nullptr}; // [0] from the band below, [1] from the band above
+    // overlap mode: the exchange of the NEXT tick's lists runs on its own stream while this
+    // tick's interior rows are still being computed (pedoni_hip_halo_tick_begin / _end)
+    bool overlap = false, in_flight = false;
+    bool lists_ready = false;   // the receive buffers already hold this tick's lists
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_recv = nullptr;
     // members of a local group (one process, one device) reach each other directly
     PedoniShard** group = nullptr;
     // initial bounds and slack every rank's map slice was cut with (pedoni_shard_map_rows): a
@@ -187,13 +193,13 @@ int shard_check(PedoniShard* s)
 const uint32_t* shard_below(const PedoniShard* s) { return s->rank > 0 ? s->d_recv_below : nullptr; }
 const uint32_t* shard_above(const PedoniShard* s) { return s->rank + 1 < s->world ? s->d_recv_above : nullptr; }
 
-// the per-tick neighbour exchange of the packed lists, on the model's stream
-int shard_exchange_rccl(PedoniShard* s)
+// the per-tick neighbour exchange of the packed lists, on the model's stream (or, in overlap
+// mode, on the shard's communication stream)
+int shard_exchange_rccl(PedoniShard* s, hipStream_t st)
 {
     if (s->world == 1) return PEDONI_OK;
     if (!s->comm) return fail(PEDONI_E_INVALID, "shard has no communicator (created without an id)");
     RcclApi& api = rccl();
-    hipStream_t st = s->m->stream;
     const size_t n = s->words_each;
     NCCL_TRY(api.GroupStart());
     if (s->rank > 0) {
@@ -362,13 +368,47 @@ struct SampledProfile {
     ~SampledProfile() { m->profile_now = true; }
 };
 
+// the lists of THIS tick: already on their way (overlap mode) or exchanged now
+int shard_get_lists(PedoniShard* s)
+{
+    if (s->in_flight) {
+        HIP_TRY(hipStreamWaitEvent(s->m->stream, s->ev_recv, 0));
+        s->in_flight = false;
+        return PEDONI_OK;
+    }
+    if (s->lists_ready) {
+        s->lists_ready = false;
+        return PEDONI_OK;
+    }
+    return shard_exchange_rccl(s, s->m->stream);
+}
+
+// overlap mode: the freshly packed lists leave on the communication stream
+int shard_start_next(PedoniShard* s)
+{
+    if (!s->overlap) return PEDONI_OK;
+    HIP_TRY(hipEventRecord(s->ev_packed, s->m->stream));
+    HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_packed, 0));
+    TRY(shard_exchange_rccl(s, s->comm_stream));
+    HIP_TRY(hipEventRecord(s->ev_recv, s->comm_stream));
+    s->in_flight = true;
+    return PEDONI_OK;
+}
+
 int shard_tick_rccl(PedoniShard* s)
 {
     PedoniModel* m = s->m;
     SampledProfile sampled(m);
-    TRY(shard_exchange_rccl(s));
+    TRY(shard_get_lists(s));
     if (!recut_due(s)) {
-        TRY(pedoni_hip_halo_tick(m, shard_below(s), shard_above(s), s->d_send, s->cap));
+        if (s->overlap) {
+            // rows beside the band's edges first, pack, send; the interior rows meanwhile
+            TRY(pedoni_hip_halo_tick_begin(m, shard_below(s), shard_above(s), s->d_send, s->cap));
+            TRY(shard_start_next(s));
+            TRY(pedoni_hip_halo_tick_end(m));
+        } else {
+            TRY(pedoni_hip_halo_tick(m, shard_below(s), shard_above(s), s->d_send, s->cap));
+        }
     } else {
         TRY(pedoni_hip_halo_unpack(m, shard_below(s), shard_above(s), s->cap));
         TRY(sort_despawn(m));
@@ -384,6 +424,7 @@ int shard_tick_rccl(PedoniShard* s)
         TRY(recut_apply(s, nb));
         TRY(update_states(m));
         TRY(shard_pack(s));
+        TRY(shard_start_next(s));
     }
     s->ticks += 1;
     return PEDONI_OK;
@@ -492,6 +533,9 @@ void pedoni_shard_destroy(PedoniShard* s)
         hipSetDevice(s->m->device);
         if (s->m->stream) hipStreamSynchronize(s->m->stream);
     }
+    if (s->comm_stream) { hipStreamSynchronize(s->comm_stream); hipStreamDestroy(s->comm_stream); }
+    if (s->ev_packed) hipEventDestroy(s->ev_packed);
+    if (s->ev_recv) hipEventDestroy(s->ev_recv);
     if (s->comm && rccl().CommDestroy) rccl().CommDestroy(s->comm);
     hipFree(s->d_send); hipFree(s->d_recv_below); hipFree(s->d_recv_above); hipFree(s->d_hist);
     for (int k = 0; k < 2; ++k) { hipFree(s->d_bulk_send[k]); hipFree(s->d_bulk_recv[k]); }
@@ -575,6 +619,26 @@ int pedoni_shard_set_rebalance(PedoniShard* s, uint32_t every_ticks, uint32_t ma
     return PEDONI_OK;
 }
 
+int pedoni_shard_set_overlap(PedoniShard* s, int32_t on)
+{
+    TRY(shard_check(s));
+    if (s->group) return fail(PEDONI_E_INVALID, "set_overlap: not for members of a local group");
+    if (s->in_flight) {                                   // settle the exchange that is under way
+        HIP_TRY(hipStreamWaitEvent(s->m->stream, s->ev_recv, 0));
+        HIP_TRY(hipStreamSynchronize(s->m->stream));
+        // its lists are in the receive buffers: the next tick must not exchange again
+        s->in_flight = false;
+        s->lists_ready = true;
+    }
+    if (on && !s->comm_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_packed, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
+    }
+    s->overlap = on != 0;
+    return PEDONI_OK;
+}
+
 int pedoni_shard_selftest(PedoniShard* s)
 {
     TRY(shard_check(s));
@@ -604,7 +668,7 @@ int pedoni_shard_selftest(PedoniShard* s)
     tok[0] = 0xD0000000u | (uint32_t)s->rank;              // first word of my DOWN list
     tok[n] = 0xA0000000u | (uint32_t)s->rank;              // first word of my UP list
     HIP_TRY(hipMemcpyAsync(s->d_send, tok.data(), tok.size() * sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
-    TRY(shard_exchange_rccl(s));
+    TRY(shard_exchange_rccl(s, m->stream));
     uint32_t got_below = 0, got_above = 0;
     if (s->rank > 0)
         HIP_TRY(hipMemcpyAsync(&got_below, s->d_recv_below + n, sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));

@@ -123,7 +123,8 @@ def test_c_shard_demo_one_rank_rccl(tmp_path):
     r = subprocess.run([str(exe), str(SCENARIO), "0", "1", str(tmp_path / "id.bin"), "300"],
                        capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stderr
-    assert r.stdout.startswith("rank=0/1 band=[0,15)")
-    before, after = (int(x) for x in r.stdout.split("owned ")[1].split(" -> "))
+    line = [l for l in r.stdout.splitlines() if l.startswith("rank=")][-1]   # (RCCL prints a banner first)
+    assert line.startswith("rank=0/1 band=[0,15)")
+    before, after = (int(x) for x in line.split("owned ")[1].split(" -> "))
     assert before > 100 and 0 <= after < before
     assert (tmp_path / "id.bin").stat().st_size == 128

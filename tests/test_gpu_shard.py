@@ -168,7 +168,11 @@ def test_one_rank_rccl_group_runs_the_direct_calls(hip, oracle):
     single.append(pos, dest, v0, vel)
     m.append(pos, dest, v0, vel)
     s.begin()
-    s.tick_n(15)
+    s.tick_n(7)
+    s.set_overlap(True)          # split tick: edge rows, pack, exchange on its own stream, interior
+    s.tick_n(5)
+    s.set_overlap(False)         # (settles the exchange under way; its lists serve the next tick)
+    s.tick_n(3)
     single.tick_n(15)
     single.sort_despawn(); m.sort_despawn()
     a, b = single.download(), m.download()
