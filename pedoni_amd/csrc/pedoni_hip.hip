@@ -533,7 +533,6 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         case 5: hipLaunchKernelGGL((force_kernel_queue_s94<0, 5>), grid, block, 0, stream, a); break;
         case 15: hipLaunchKernelGGL((force_kernel_queue<0, 5>), grid, block, 0, stream, a); break;
         case 16: hipLaunchKernelGGL((force_kernel_queue_s94<0, 6>), grid, block, 0, stream, a); break;
-        case 17: hipLaunchKernelGGL((force_kernel_queue_s94<0, 7>), grid, block, 0, stream, a); break;
         case 18: hipLaunchKernelGGL((force_kernel_queue_s94<0, 8>), grid, block, 0, stream, a); break;
         case 116: hipLaunchKernelGGL((force_kernel_queue_s94<1, 6>), grid, block, 0, stream, a); break;
         case 8: hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, stream, a); break;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # force-kernel queue depth / residency sweep: PEDONI_FORCE_SLOTS = 6 (default), 5 and 4 (94-SGPR
 # kernels: 7 workgroups per CU), 15 (5 slots, default SGPRs).  bash tools/slots_sweep.sh [bench args]
-for S in 16 6 5 15 4 18 8; do
+for S in ${SLOTS_LIST:-16 6 5 15 4 18 8}; do
   for MODE in exact fast; do
     PEDONI_FORCE_SLOTS=$S python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-fast-leg --math $MODE "$@" 2>/dev/null | python3 -c "
 import json,sys
