@@ -489,8 +489,7 @@ __device__ __forceinline__ uint32_t pair_force_hot(v2 difference, v2 e, v2 vel_i
 // 1-ulp error of sqrt/rcp would be amplified up to 1000-fold.  The goal direction `e` is
 // exact in both modes.  Every agent then meets the 1e-5 bar; no decision flips.
 template <int MODE>
-__device__ __forceinline__ void pair_force_from_difference(v2 difference, v2 e, v2 vel_i, float vl, v2& acc,
-                                                           const uint64_t* tab)
+__device__ __forceinline__ v2 pair_force_value(v2 difference, v2 e, v2 vel_i, float vl, const uint64_t* tab)
 {
     bool redo;
     v2 force;
@@ -515,7 +514,14 @@ __device__ __forceinline__ void pair_force_from_difference(v2 difference, v2 e, 
     }
     if (lhs < rhs)                                       // :149
         force = force * 0.5f;                            // :150
-    acc = acc + force;                                   // :153
+    return force;
+}
+
+template <int MODE>
+__device__ __forceinline__ void pair_force_from_difference(v2 difference, v2 e, v2 vel_i, float vl, v2& acc,
+                                                           const uint64_t* tab)
+{
+    acc = acc + pair_force_value<MODE>(difference, e, vel_i, vl, tab);   // :153
 }
 
 template <int MODE>

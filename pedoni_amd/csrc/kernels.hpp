@@ -833,8 +833,8 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
             const float eo_x = __shfl(e.x, own, 64), eo_y = __shfl(e.y, own, 64);
             if (busy) {
                 float2 en = queue[q];
-                v2 f = mk(0.0f, 0.0f);
-                pair_force_from_difference<MODE>(mk(en.x, en.y), mk(eo_x, eo_y), mk(vn.x, vn.y), vn.z, f, tab);
+                // the force itself (the owner's `acc += force` of sfm.rs:153 happens in phase 3)
+                const v2 f = pair_force_value<MODE>(mk(en.x, en.y), mk(eo_x, eo_y), mk(vn.x, vn.y), vn.z, tab);
                 queue[q] = make_float2(f.x, f.y);
             }
         }
