@@ -36,6 +36,25 @@ def test_balanced_bounds_is_pure_host_code():
         abi.balanced_bounds(counts, 60, min_rows=2)
 
 
+def test_shard_map_rows_cover_the_band_its_ghosts_and_the_stencil():
+    """pedoni_shard_map_rows (pure host code): the texel rows a band uploads contain every row a
+    4 x 4 stencil can touch from a position in grid rows [lo - 2, hi + 2) -- ghost row, one
+    tick's step and the patch's apron -- are clamped to the field, and grow with the slack."""
+    unit, gunit, frows = 0.25, 1.4, 32000
+    for lo, hi in [(0, 89), (89, 178), (2857, 2946), (5626, 5715)]:
+        a, b = abi.shard_map_rows(lo, hi, 0, gunit, unit, frows)
+        assert 0 <= a < b <= frows
+        for y in (max((lo - 2) * gunit, 0.0), min((hi + 2) * gunit, frows * unit) - 1e-3):
+            q = np.float32(y) / np.float32(unit) - np.float32(0.5)
+            y0 = int(np.floor(q - 1))                    # base texel of the tap at offset -1
+            assert a <= max(y0, 0) and min(y0 + 3, frows - 1) < b, (lo, hi, y, a, b)
+        a2, b2 = abi.shard_map_rows(lo, hi, 4, gunit, unit, frows)
+        assert a2 <= a and b2 >= b and (b2 - a2) >= (b - a)
+    assert abi.shard_map_rows(0, 5715, 0, gunit, unit, frows) == (0, frows)
+    with pytest.raises(abi.PedoniError):
+        abi.shard_map_rows(5, 5, 0, gunit, unit, frows)
+
+
 def test_hip_library_exports_every_declared_symbol():
     lib = abi.load_library()
     declared = _declared("pedoni_hip.h", "pedoni_(?:hip|shard)")
