@@ -255,6 +255,13 @@ int pedoni_shard_map_rows(int32_t row_begin, int32_t row_end, int32_t slack_rows
                           uint32_t* map_row_end);
 int pedoni_shard_balanced_bounds(const uint32_t* row_counts, uint32_t n_rows, int32_t world,
                                  int32_t min_rows, int32_t* bounds_out /* world + 1 */);
+/* one step of the periodic re-cut (pure host code; what every rank computes from the all-reduced
+ * per-row counts): each boundary moves towards the agent-balanced cut by at most `max_shift`
+ * rows, bands keep >= 6 rows, the rows handed over fit `bulk_cap` agents, and -- with
+ * `map_slack_rows` >= 0 -- no boundary leaves bounds0[b] +- that slack */
+int pedoni_shard_recut_bounds(const int32_t* bounds, int32_t world, const uint32_t* row_counts,
+                              uint32_t n_rows, uint32_t max_shift, uint32_t bulk_cap,
+                              const int32_t* bounds0, int32_t map_slack_rows, int32_t* bounds_out);
 /* `id` NULL: no communicator (world == 1, or a member of a local group, below).  The model
  * must hold no agents; it is given the band [row_bounds[rank], row_bounds[rank+1]). */
 int pedoni_shard_create(PedoniModel* m, int32_t rank, int32_t world, const uint8_t* id,

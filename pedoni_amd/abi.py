@@ -41,7 +41,7 @@ SYMBOLS = [
     "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_selftest_field", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
     "pedoni_hip_debug_set_status", "pedoni_hip_profile_every",
     "pedoni_hip_create_rows", "pedoni_shard_map_rows", "pedoni_hip_eikonal",
-    "pedoni_shard_unique_id", "pedoni_shard_balanced_bounds", "pedoni_shard_create", "pedoni_shard_destroy",
+    "pedoni_shard_unique_id", "pedoni_shard_balanced_bounds", "pedoni_shard_recut_bounds", "pedoni_shard_create", "pedoni_shard_destroy",
     "pedoni_shard_begin", "pedoni_shard_tick_n", "pedoni_shard_owned_count", "pedoni_shard_band",
     "pedoni_shard_selftest", "pedoni_shard_set_rebalance", "pedoni_shard_set_overlap", "pedoni_shard_local_group_tick_n",
 ]
@@ -448,6 +448,20 @@ def balanced_bounds(row_counts, world: int, min_rows: int = 6) -> list:
     out = (C.c_int32 * (world + 1))()
     _check(lib, lib.pedoni_shard_balanced_bounds(rc.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(len(rc)),
                                                  C.c_int32(world), C.c_int32(min_rows), out))
+    return list(out)
+
+
+def recut_bounds(bounds, row_counts, max_shift: int, bulk_cap: int, bounds0=None, map_slack_rows: int = -1) -> list:
+    """One step of the periodic re-cut (pure host code; pedoni_shard_recut_bounds)."""
+    lib = load_library()
+    world = len(bounds) - 1
+    b = (C.c_int32 * (world + 1))(*[int(x) for x in bounds])
+    b0 = (C.c_int32 * (world + 1))(*[int(x) for x in (bounds0 if bounds0 is not None else bounds)])
+    rc = np.ascontiguousarray(row_counts, np.uint32)
+    out = (C.c_int32 * (world + 1))()
+    _check(lib, lib.pedoni_shard_recut_bounds(b, C.c_int32(world), rc.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                              C.c_uint32(len(rc)), C.c_uint32(max_shift), C.c_uint32(bulk_cap), b0,
+                                              C.c_int32(map_slack_rows), out))
     return list(out)
 
 

@@ -174,12 +174,6 @@ struct PedoniShard {
     // re-cut may move boundary b only where both adjoining bands still fit their slices
     std::vector<int32_t> bounds0;
     int32_t slice_slack = -1;          // < 0: whole maps on the device, no constraint
-    bool fits(int32_t b, int32_t to) const
-    {
-        if (slice_slack < 0) return true;
-        // band b-1 = [.., to) was cut for rows up to bounds0[b] + slack; band b = [to, ..) from bounds0[b] - slack
-        return to <= bounds0[b] + slice_slack && to >= bounds0[b] - slice_slack;
-    }
 };
 
 namespace {
@@ -239,38 +233,13 @@ int recut_hist(PedoniShard* s)
     return PEDONI_OK;
 }
 
-// the cut itself: same input, same result on every rank.  Boundaries move at most max_shift
-// rows per re-cut, never past a neighbour's rows that are not there to hand over, bands keep
-// >= 6 rows, and no transfer exceeds the bulk list capacity.
+// the cut itself: same input, same result on every rank (pedoni_shard_recut_bounds: pure host
+// code, tested on the CPU)
 void recut_bounds(const PedoniShard* s, const uint32_t* hist, std::vector<int32_t>& nb)
 {
-    const int32_t n_rows = s->m->grid.rows, world = s->world;
-    std::vector<int32_t> ideal((size_t)world + 1);
-    pedoni_shard_balanced_bounds(hist, (uint32_t)n_rows, world, 6, ideal.data());
-    nb = s->bounds;
-    const int32_t min_rows = 6;
-    for (int32_t b = 1; b < world; ++b) {
-        const int32_t old = s->bounds[b];
-        int32_t want = std::max(old - (int32_t)s->max_shift, std::min(old + (int32_t)s->max_shift, ideal[b]));
-        // stay inside the rows both neighbours held BEFORE the cut, keep every band >= min_rows
-        want = std::max(want, std::max(s->bounds[b - 1] + min_rows, nb[b - 1] + min_rows));
-        want = std::min(want, s->bounds[b + 1] - min_rows);
-        if (want < nb[b - 1] + min_rows) want = old;      // cannot satisfy both: leave it
-        // a band that holds only a slice of the field maps must stay inside it (both bands that
-        // meet at this boundary are checked by their own ranks alike: the slices are symmetric
-        // functions of the initial bounds, so every rank evaluates the same predicate)
-        while (want != old && !s->fits(b, want)) want += want < old ? 1 : -1;
-        // the rows handed over must fit one bulk list
-        auto moved = [&](int32_t to) {
-            uint64_t n = 0;
-            // donor sends rows [to-1, old-1) when the cut moves down, [old+1, to+1) when it moves up
-            const int32_t a = to < old ? to - 1 : old + 1, e = to < old ? old - 1 : to + 1;
-            for (int32_t r = std::max(a, 0); r < std::min(e, n_rows); ++r) n += hist[r];
-            return n;
-        };
-        while (want != old && moved(want) > s->bulk_cap) want += want < old ? 1 : -1;
-        nb[b] = want;
-    }
+    nb.assign(s->bounds.size(), 0);
+    pedoni_shard_recut_bounds(s->bounds.data(), s->world, hist, (uint32_t)s->m->grid.rows, s->max_shift,
+                              s->bulk_cap, s->bounds0.data(), s->slice_slack, nb.data());
 }
 
 // phase 2: pack the rows this band hands over (old bounds), as decided by every rank alike
@@ -459,6 +428,44 @@ int pedoni_shard_map_rows(int32_t row_begin, int32_t row_end, int32_t slack_rows
     const double t0 = std::floor(y0 / field_unit - 0.5) - 3.0, t1 = std::ceil(y1 / field_unit - 0.5) + 4.0;
     *map_row_begin = (uint32_t)std::max(0.0, std::min(t0, (double)field_rows - 1.0));
     *map_row_end = (uint32_t)std::max((double)*map_row_begin + 1.0, std::min(t1, (double)field_rows));
+    return PEDONI_OK;
+}
+
+int pedoni_shard_recut_bounds(const int32_t* bounds, int32_t world, const uint32_t* row_counts, uint32_t n_rows,
+                              uint32_t max_shift, uint32_t bulk_cap, const int32_t* bounds0, int32_t map_slack_rows,
+                              int32_t* bounds_out)
+{
+    const int32_t min_rows = 6;
+    if (!bounds || !row_counts || !bounds_out || world < 1 || (map_slack_rows >= 0 && !bounds0))
+        return fail(PEDONI_E_INVALID, "recut_bounds: bad arguments");
+    for (int32_t b = 0; b <= world; ++b) bounds_out[b] = bounds[b];
+    if ((uint64_t)world * (uint64_t)min_rows > n_rows) return PEDONI_OK;      // too few rows to move anything
+    std::vector<int32_t> ideal((size_t)world + 1);
+    TRY(pedoni_shard_balanced_bounds(row_counts, n_rows, world, min_rows, ideal.data()));
+    for (int32_t b = 1; b < world; ++b) {
+        const int32_t old = bounds[b];
+        int32_t want = std::max(old - (int32_t)max_shift, std::min(old + (int32_t)max_shift, ideal[b]));
+        // the donor hands over rows it held BEFORE the cut; every band keeps >= min_rows
+        want = std::max(want, std::max(bounds[b - 1] + min_rows, bounds_out[b - 1] + min_rows));
+        want = std::min(want, bounds[b + 1] - min_rows);
+        if (want < bounds_out[b - 1] + min_rows) want = old;                 // cannot satisfy both: leave it
+        // bands that hold a slice of the field maps stay inside it: every rank cut its slice from
+        // the INITIAL bounds with the same slack, so every rank evaluates the same predicate
+        auto fits = [&](int32_t to) {
+            return map_slack_rows < 0 || (to <= bounds0[b] + map_slack_rows && to >= bounds0[b] - map_slack_rows);
+        };
+        while (want != old && !fits(want)) want += want < old ? 1 : -1;
+        // the rows handed over must fit one bulk list: the donor sends rows [to-1, old-1) when the
+        // cut moves down, [old+1, to+1) when it moves up
+        auto moved = [&](int32_t to) {
+            uint64_t n = 0;
+            const int32_t a = to < old ? to - 1 : old + 1, e = to < old ? old - 1 : to + 1;
+            for (int32_t r = std::max(a, 0); r < std::min(e, (int32_t)n_rows); ++r) n += row_counts[r];
+            return n;
+        };
+        while (want != old && moved(want) > bulk_cap) want += want < old ? 1 : -1;
+        bounds_out[b] = want;
+    }
     return PEDONI_OK;
 }
 
