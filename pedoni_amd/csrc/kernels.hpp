@@ -705,8 +705,10 @@ template <int MODE, int SLOTS>
 __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
 {
     __shared__ uint64_t tab[32];
-    __shared__ float2 queue_all[FORCE_WAVES][SLOTS * 64];    // {dx, dy} in, {fx, fy} out
-    __shared__ uint32_t who_all[FORCE_WAVES][SLOTS * 64];    // neighbour index | owner lane << 26
+    // (+ 64 entries per wave: lane l of a slot that did not pass writes entry SLOTS * 64 + l, so
+    // the queue writes of phase 1 need no branch)
+    __shared__ float2 queue_all[FORCE_WAVES][SLOTS * 64 + 64];    // {dx, dy} in, {fx, fy} out
+    __shared__ uint32_t who_all[FORCE_WAVES][SLOTS * 64 + 64];    // neighbour index | owner lane << 26
     if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
     __syncthreads();
 
@@ -811,10 +813,9 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             const uint32_t slot = qlen + before;
             slot_of[k] = pass ? slot : 0xffffffffu;
-            if (pass) {
-                queue[slot] = make_float2(dx, dy);
-                who[slot] = idx[k] | (lane << 26);
-            }
+            const uint32_t at = pass ? slot : (uint32_t)(SLOTS * 64) + lane;
+            queue[at] = make_float2(dx, dy);
+            who[at] = idx[k] | (lane << 26);
             qlen += (uint32_t)__popcll(mask);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -842,12 +843,18 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         __builtin_amdgcn_wave_barrier();
 
         // ---- phase 3: ordered accumulation (sfm.rs:153) ---------------------------------
+        // all SLOTS results are fetched first (a slot that did not pass reads entry 0: a valid
+        // address, value unused), then added in candidate order under a select: no branch and
+        // no LDS round trip per slot
+        float2 fr[SLOTS];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) fr[k] = queue[min(slot_of[k], (uint32_t)(SLOTS * 64 - 1))];
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
-            if (slot_of[k] != 0xffffffffu) {
-                float2 f = queue[slot_of[k]];
-                acc = acc + mk(f.x, f.y);
-            }
+            const bool passed = slot_of[k] != 0xffffffffu;
+            const v2 sum = acc + mk(fr[k].x, fr[k].y);
+            acc.x = passed ? sum.x : acc.x;
+            acc.y = passed ? sum.y : acc.y;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
