@@ -307,6 +307,11 @@ int pedoni_hip_eikonal(int device, float* potential, const float* slowness, floa
  * bound of the arrays).  While it is non-zero every read of device state -- get_pedestrian_count,
  * download, list_pedestrians, owned_count -- fails with PEDONI_E_HIP / PEDONI_E_CAPACITY. */
 int pedoni_hip_debug_set_status(PedoniModel* m, uint32_t status_word);
+/* [ext] diagnostic: a model created under PEDONI_FORCE_TRACE=1 runs an instrumented build of the
+ * force kernel (never the product kernel) whose waves add the shader cycles they spent in the
+ * prologue, phases 1 / 2 / 3 and the epilogue (sums7[0..4]), their lifetimes ([5]) and their
+ * number ([6]); tools/force_trace.py prints the shares */
+int pedoni_hip_debug_force_trace(PedoniModel* m, uint64_t* sums7, int32_t reset);
 
 /* [ext] device self-test hooks used by tests/: evaluate one device math primitive over
  * host arrays (op: 0 = a/b, 1 = sqrt(a), 2 = exp(a), 3 = a/0.3f, 4 = a/0.2f,

@@ -536,6 +536,7 @@ struct ForceArgs {
     SortFlags* flags;
     uint32_t parity_next;
     int32_t xcd_remap; // XCD-contiguous block order (PEDONI_NO_XCD_REMAP=1 turns it off)
+    unsigned long long* trace; // TRACE build only (7 words, see force_queue_body)
     int32_t ablate; // diagnostics only (PEDONI_ABLATE): 1 = no goal sampling, 2 = no obstacle term, 4 = no pairs
 };
 
@@ -701,9 +702,34 @@ __global__ void force_kernel_simple(ForceArgs a)
 constexpr int FORCE_THREADS = 256;
 constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 
-template <int MODE, int SLOTS>
+// TRACE (diagnostic build, PEDONI_FORCE_TRACE=1, never the product kernel): every wave adds the
+// shader cycles (s_memtime) it spent in the prologue, in phases 1 / 2 / 3 and in the epilogue to
+// its own record a.trace[8 * wave + 0..4], its lifetime to [5] and 1 to [6] -- where a wave's
+// WALL time goes, waiting and being passed over by the arbiter included.
+template <int MODE, int SLOTS, bool TRACE = false>
 __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
 {
+    unsigned long long tr_t0 = 0, tr_mark = 0, tr_acc[5] = {0, 0, 0, 0, 0};
+    auto tr_lap = [&](int which) {
+        if constexpr (TRACE) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tr_acc[which] += now - tr_mark;
+            tr_mark = now;
+        }
+    };
+    auto tr_flush = [&]() {
+        if constexpr (TRACE) {
+            if ((threadIdx.x & 63u) == 0 && a.trace) {
+                tr_lap(4);
+                // one 64-byte record per wave (plain stores: atomics on shared words would stall the run)
+                unsigned long long* rec = a.trace + 8ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+                for (int k = 0; k < 5; ++k) rec[k] += tr_acc[k];
+                rec[5] += __builtin_amdgcn_s_memtime() - tr_t0;
+                rec[6] += 1ull;
+            }
+        }
+    };
+    if constexpr (TRACE) tr_t0 = tr_mark = __builtin_amdgcn_s_memtime();
     __shared__ uint64_t tab[32];
     // (+ 64 entries per wave: lane l of a slot that did not pass writes entry SLOTS * 64 + l, so
     // the queue writes of phase 1 need no branch)
@@ -782,6 +808,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
     // address, already in cache): phase 1 then has no divergent branch around its loads
     const uint32_t id_safe = valid ? id : a.base;
 
+    tr_lap(0);
     for (uint32_t base = 0; base < max_cnt; base += SLOTS) {
         // ---- phase 1: cutoff test + compaction ---------------------------------------
         // three unrolled sub-passes so that the SLOTS position loads, then the SLOTS
@@ -820,6 +847,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        tr_lap(1);
 
         // ---- phase 2: one pair force per lane, no divergence ------------------------------
         for (uint32_t q0 = 0; q0 < qlen; q0 += 64) {
@@ -841,6 +869,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        tr_lap(2);
 
         // ---- phase 3: ordered accumulation (sfm.rs:153) ---------------------------------
         // all SLOTS results are fetched first (a slot that did not pass reads entry 0: a valid
@@ -858,11 +887,16 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        tr_lap(3);
     }
 
     if (!valid) {
         // slot of a despawned agent (whole-array launches only: segments end at live agents)
         if (a.key_next && a.seg_row[0][0] < 0 && id < a.key_end) a.key_next[id] = DEAD;
+    }
+    // (the epilogue below runs per lane; the trace is flushed by lane 0 wherever it leaves)
+    if (!valid) {
+        tr_flush();
         return;
     }
     if (ghost) {                                                  // ghost row: never integrated
@@ -872,6 +906,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
             a.velx_out[id] = vv;
             if (a.key_next) a.key_next[id] = DEAD;
         }
+        tr_flush();
         return;
     }
 
@@ -879,7 +914,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
     else if (a.use_distance_map) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
     else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
 
-    if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); return; }
+    if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); tr_flush(); return; }
 
     // integrator, sfm.rs:245-254
     v2 vel_prev = vel;
@@ -909,6 +944,15 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         a.key_next[id] = k;
         count_key(a.cell_count, a.row_count, k != DEAD, k, (uint32_t)cy);
     }
+    tr_flush();
+}
+
+// diagnostic build of the 7-wave kernel with per-phase cycle accounting (see TRACE above)
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_trace(ForceArgs a)
+{
+    force_queue_body<MODE, SLOTS, true>(a);
 }
 
 template <int MODE, int SLOTS>

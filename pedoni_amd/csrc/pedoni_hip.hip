@@ -42,6 +42,8 @@ int fail(int code, const std::string& msg)
         if (rc_ != PEDONI_OK) return rc_;                                                    \
     } while (0)
 
+constexpr size_t TRACE_WAVES = 1u << 18;   // PEDONI_FORCE_TRACE: one 64-byte record per wave, up to 16.7 M agents
+
 const char* const KERNEL_NAMES[PEDONI_N_KERNELS] = {
     "bin", "scan", "slot", "reorder", "force_integrate", "halo_pack", "halo_unpack", "other",
 };
@@ -147,6 +149,7 @@ struct PedoniModel {
     bool sort_general = false; // PEDONI_SORT_GENERAL=1: always take the atomic (general) sort form
     bool no_fuse_key = false;  // PEDONI_NO_FUSE_KEY=1: standalone K_KEY every tick
     bool xcd_remap = true;     // PEDONI_NO_XCD_REMAP=1: hardware block order
+    unsigned long long* d_trace = nullptr; // PEDONI_FORCE_TRACE=1: per-phase cycle sums of the force kernel
     int force_slots = 0;       // PEDONI_FORCE_SLOTS: candidates per lane per batch (0 = by size; 4, 5, 6, 8)
 
     // steady-state tick pair captured as a hipGraph (pedoni_hip_tick_n); see tick_graph()
@@ -475,6 +478,7 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
     a.use_grid = m->opt.use_neighbor_grid;
     a.use_distance_map = m->opt.use_distance_map;
     a.ablate = m->ablate;
+    a.trace = m->d_trace;
     a.xcd_remap = m->xcd_remap ? 1 : 0;
     a.seg_row[0][0] = -1; a.seg_row[0][1] = a.seg_row[1][0] = a.seg_row[1][1] = 0;
     a.clear_stale = 0;
@@ -528,12 +532,15 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         // 4 / 5 (s94), 6, 8, 15 (5 slots, default SGPRs), 16 / 18 (s94 with 6 / 8 slots).
         int slots = m->force_slots;
         if (slots == 0) slots = n >= 400000u ? 16 : 6;
+        if (m->d_trace && (size_t)grid.x * FORCE_WAVES <= TRACE_WAVES) slots = 96;
         switch (slots + (fast ? 100 : 0)) {
         case 4: hipLaunchKernelGGL((force_kernel_queue_s94<0, 4>), grid, block, 0, stream, a); break;
         case 5: hipLaunchKernelGGL((force_kernel_queue_s94<0, 5>), grid, block, 0, stream, a); break;
         case 15: hipLaunchKernelGGL((force_kernel_queue<0, 5>), grid, block, 0, stream, a); break;
         case 16: hipLaunchKernelGGL((force_kernel_queue_s94<0, 6>), grid, block, 0, stream, a); break;
         case 18: hipLaunchKernelGGL((force_kernel_queue_s94<0, 8>), grid, block, 0, stream, a); break;
+        case 96: hipLaunchKernelGGL((force_kernel_queue_trace<0, 6>), grid, block, 0, stream, a); break;
+        case 196: hipLaunchKernelGGL((force_kernel_queue_trace<1, 6>), grid, block, 0, stream, a); break;
         case 116: hipLaunchKernelGGL((force_kernel_queue_s94<1, 6>), grid, block, 0, stream, a); break;
         case 8: hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, stream, a); break;
         case 104: hipLaunchKernelGGL((force_kernel_queue_s94<1, 4>), grid, block, 0, stream, a); break;
@@ -738,6 +745,14 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
         m->no_fuse_key = nf && nf[0] == '1';
         const char* nx = std::getenv("PEDONI_NO_XCD_REMAP");
         m->xcd_remap = !(nx && nx[0] == '1');
+        const char* ft = std::getenv("PEDONI_FORCE_TRACE");
+        if (ft && ft[0] == '1') {
+            if (hipMalloc((void**)&m->d_trace, TRACE_WAVES * 8 * sizeof(unsigned long long)) != hipSuccess ||
+                hipMemset(m->d_trace, 0, TRACE_WAVES * 8 * sizeof(unsigned long long)) != hipSuccess) {
+                pedoni_hip_destroy(m);
+                return fail(PEDONI_E_HIP, "create: trace buffer");
+            }
+        }
         const char* ng = std::getenv("PEDONI_NO_GRAPH");
         m->use_graph = !(ng && ng[0] == '1');
         const char* fsl = std::getenv("PEDONI_FORCE_SLOTS");
@@ -850,6 +865,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     hipFree(m->d_live); hipFree(m->d_acc); hipFree(m->d_halo);
     hipFree(m->d_spawners); hipFree(m->d_spawn_state);
     hipFree(m->d_row_count);
+    hipFree(m->d_trace);
     if (m->h_pinned) hipHostFree(m->h_pinned);
     hipFree(m->d_distance_map);
     for (float* p : m->d_pot) hipFree(p);
@@ -1456,6 +1472,22 @@ int pedoni_hip_owned_count(PedoniModel* m, int32_t* count)
     if (h.error & 8u)
         return fail(PEDONI_E_CAPACITY, "a tick spawned more agents than max_per_tick");
     *count = (int32_t)(hi - lo);
+    return PEDONI_OK;
+}
+
+int pedoni_hip_debug_force_trace(PedoniModel* m, uint64_t* sums7, int32_t reset)
+{
+    TRY(bind(m));
+    if (!m->d_trace) return fail(PEDONI_E_INVALID, "force trace: create the model with PEDONI_FORCE_TRACE=1");
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (sums7) {
+        std::vector<unsigned long long> rec(TRACE_WAVES * 8);
+        HIP_TRY(hipMemcpy(rec.data(), m->d_trace, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 7; ++k) sums7[k] = 0;
+        for (size_t w = 0; w < TRACE_WAVES; ++w)
+            for (int k = 0; k < 7; ++k) sums7[k] += rec[8 * w + k];
+    }
+    if (reset) HIP_TRY(hipMemset(m->d_trace, 0, TRACE_WAVES * 8 * sizeof(unsigned long long)));
     return PEDONI_OK;
 }
 
