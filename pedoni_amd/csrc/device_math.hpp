@@ -36,10 +36,9 @@ template <int MODE> __device__ __forceinline__ float frcp(float b)
 }
 // Correctly rounded sqrt.  hipcc's expansion of sqrtf is v_sqrt_f32 (1 ulp) plus a one-ulp
 // correction from two fma residuals, wrapped in a 2^32 rescale for x < 2^-96 and a class test
-// for 0 / inf / NaN: 16 VALU instructions.  For 2^-96 <= x < inf the wrap is the identity,
-// so the bare correction (sqrt_core) gives the very same bits; anything else (0, denormal,
-// tiny, negative, inf, NaN) takes the compiler's form.  Checked against the host's sqrtf on
-// every non-negative float (tools/exhaustive_sqrt.py).
+// for 0 / inf / NaN: 16 VALU instructions.  For 2^-96 <= x < inf sqrt_core below gives the very
+// same bits in 5; anything else (0, denormal, tiny, negative, inf, NaN) takes the compiler's
+// form.  Checked against the host's sqrtf on every non-negative float (tools/exhaustive_sqrt.py).
 __device__ __noinline__ float sqrt_generic(float a) { return __builtin_sqrtf(a); }
 constexpr uint32_t SQRT_CORE_LO = 0x0F800000u;   // bits of 2^-96
 constexpr uint32_t SQRT_CORE_SPAN = 0x70000000u; // up to, not including, +inf
@@ -47,14 +46,14 @@ constexpr uint32_t SQRT_CORE_SPAN = 0x70000000u; // up to, not including, +inf
 __device__ __forceinline__ uint32_t sqrt_core_measure(float a) { return __float_as_uint(a) - SQRT_CORE_LO; }
 __device__ __forceinline__ float sqrt_core(float a)
 {
-    float s = __builtin_amdgcn_sqrtf(a);
-    float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
-    float s_up = __uint_as_float(__float_as_uint(s) + 1u);
-    float r_dn = __builtin_fmaf(-s_dn, s, a);
-    float r_up = __builtin_fmaf(-s_up, s, a);
-    s = r_dn <= 0.0f ? s_dn : s;
-    s = r_up > 0.0f ? s_up : s;
-    return s;
+    // v_rsq_f32 (1 ulp) and ONE residual step: g = a * y, h = y / 2, s = g + (a - g * g) * h.
+    // Equal to the correctly rounded square root -- the bits of the compiler's own expansion
+    // (v_sqrt_f32 and a test of both neighbours, 9 instructions) -- for EVERY float in
+    // [2^-96, +inf): tools/microbench/sqrt_variants.hip compares all 1 879 048 192 of them.
+    float y = __builtin_amdgcn_rsqf(a);
+    float g = a * y, h = 0.5f * y;
+    float d = __builtin_fmaf(-g, g, a);
+    return __builtin_fmaf(d, h, g);
 }
 __device__ __forceinline__ float sqrt_rn(float a)
 {
@@ -361,6 +360,14 @@ __device__ __forceinline__ v2 field_coord(const FieldView& f, v2 pos)
 // reciprocal part is shared by quotients with one denominator.  pair_force_hot guarantees
 // that domain through its folded range test (it rejects quotients below 2^-50, which covers
 // every numerator small enough to be rescaled).
+// Two things about that sequence on gfx950, both established by exhaustive runs on the device
+// (tools/microbench/sqrt_variants.hip, div_variants.hip) and used below:
+//  - the refined reciprocal y = fma(fma(-d, rcp(d), 1), rcp(d), rcp(d)) IS RN(1 / d) for every d in
+//    [2^-125, 2^126) (all 2 105 540 608 floats), so 1 / d needs no quotient correction at all;
+//  - with that y, ONE quotient correction already gives the final quotient: the second never
+//    changes it, for all 2^23 x 2^23 pairs of significands (in the domain above no operand or
+//    residual under- or overflows, every operation scales exactly with powers of two, and the
+//    quotient's significand depends on the two significands only).
 struct Recip { float d, y; };
 __device__ __forceinline__ Recip recip_refined(float d)
 {
@@ -375,8 +382,6 @@ __device__ __forceinline__ float div_core(float n, Recip r)
 {
     float q = n * r.y;
     float e = __builtin_fmaf(-r.d, q, n);
-    q = __builtin_fmaf(e, r.y, q);
-    e = __builtin_fmaf(-r.d, q, n);
     return __builtin_fmaf(e, r.y, q);
 }
 
@@ -441,7 +446,7 @@ __device__ __forceinline__ uint32_t pair_force_hot(v2 difference, v2 e, v2 vel_i
     float distance_squared = dot(difference, difference); // :132
     uint32_t worst = sqrt_core_measure(distance_squared);
     float distance = sqrt_core(distance_squared);        // :137
-    v2 direction = difference * div_core(1.0f, recip_refined(distance)); // :138 normalize()
+    v2 direction = difference * recip_refined(distance).y; // :138 normalize(): difference * RN(1 / distance)
 
     v2 t1 = difference - vel_i * 0.1f;                   // :141
     float t1_sq = dot(t1, t1);
