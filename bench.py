@@ -396,10 +396,10 @@ def main() -> None:
     sharded = runner is not None or shard is not None
     n_before = model.owned_count() if sharded else model.get_pedestrian_count()
     if not args.no_profile:
-        # inside the timed region the dominant kernel is event-timed on every 8th tick only:
+        # inside the timed region the dominant kernel is event-timed on every 9th tick only (an odd period: the 8 ticks between two timed ones replay as 4 captured pairs):
         # timed ticks launch eagerly (+ one hipEvent pair), the others replay the captured tick
         # pair; the full per-kernel breakdown is a separate pass after the timed region
-        model.profile(True, kernels=[abi.K_FORCE], every=8)
+        model.profile(True, kernels=[abi.K_FORCE], every=9)
         model.kernel_times(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -477,7 +477,7 @@ def main() -> None:
             fm.tick_n(args.warmup)
             fm.synchronize()
             nb = fm.get_pedestrian_count()
-            fm.profile(True, kernels=[abi.K_FORCE], every=8)
+            fm.profile(True, kernels=[abi.K_FORCE], every=9)
             fm.kernel_times(reset=True)
             t0 = time.perf_counter()
             fm.tick_n(args.steps)

@@ -814,7 +814,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         // three unrolled sub-passes so that the SLOTS position loads, then the SLOTS
         // velocity loads, are all in flight together
         uint32_t qlen = 0;       // wave-uniform
-        uint32_t slot_of[SLOTS]; // queue slot of candidate k, or ~0 when it did not pass
+        uint32_t at_of[SLOTS];   // queue entry of candidate k: its slot, or this lane's dump entry
         uint32_t idx[SLOTS];
         float2 d[SLOTS];
 #pragma unroll
@@ -830,21 +830,26 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
             float dx = pos.x - d[k].x;                            // :131
             float dy = pos.y - d[k].y;
             float d2 = (dx * dx) + (dy * dy);                     // :132
-            // :130,133 (idx == id also marks "no candidate in this slot")
-            // (two ballots of plain compares: hipcc re-materialises a ballot of their conjunction
-            // through a VGPR, two VALU instructions per slot)
-            const bool near = !(d2 > 4.0f), other = idx[k] != id_safe;
-            const bool pass = near && other;
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(near) & __builtin_amdgcn_ballot_w64(other);
+            // :130,133 (idx == id also marks "no candidate in this slot").  The two lane masks are
+            // taken straight from the compares (hipcc re-materialises a ballot of a bool with two
+            // uses through a VGPR: two more VALU instructions per slot) and so is the select.
+            unsigned long long m_near, m_other;
+            asm("v_cmp_nlt_f32_e64 %0, 4.0, %1" : "=s"(m_near) : "v"(d2));            // !(d2 > 4): NaN passes, as upstream
+            asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(m_other) : "v"(idx[k]), "v"(id_safe));
+            const unsigned long long mask = m_near & m_other;
             const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            const uint32_t slot = qlen + before;
-            slot_of[k] = pass ? slot : 0xffffffffu;
-            const uint32_t at = pass ? slot : (uint32_t)(SLOTS * 64) + lane;
+            uint32_t at;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(at) : "v"((uint32_t)(SLOTS * 64) + lane), "v"(qlen + before), "s"(mask));
+            at_of[k] = at;
             queue[at] = make_float2(dx, dy);
             who[at] = idx[k] | (lane << 26);
             qlen += (uint32_t)__popcll(mask);
         }
+        // the dump entry now reads -0: phase 3 adds it for every slot that did not pass, and
+        // x + (-0) == x bit for bit for every x (+-0, denormals -- preserved in this build -- and NaN
+        // included), so the ordered sum needs neither a test nor a select per slot
+        queue[(uint32_t)(SLOTS * 64) + lane] = make_float2(-0.0f, -0.0f);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         tr_lap(1);
@@ -872,19 +877,13 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         tr_lap(2);
 
         // ---- phase 3: ordered accumulation (sfm.rs:153) ---------------------------------
-        // all SLOTS results are fetched first (a slot that did not pass reads entry 0: a valid
-        // address, value unused), then added in candidate order under a select: no branch and
-        // no LDS round trip per slot
+        // all SLOTS entries are fetched first (a slot that did not pass reads the lane's dump
+        // entry, -0), then added in candidate order: no branch, no select, no LDS round trip per slot
         float2 fr[SLOTS];
 #pragma unroll
-        for (int k = 0; k < SLOTS; ++k) fr[k] = queue[min(slot_of[k], (uint32_t)(SLOTS * 64 - 1))];
+        for (int k = 0; k < SLOTS; ++k) fr[k] = queue[at_of[k]];
 #pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            const bool passed = slot_of[k] != 0xffffffffu;
-            const v2 sum = acc + mk(fr[k].x, fr[k].y);
-            acc.x = passed ? sum.x : acc.x;
-            acc.y = passed ? sum.y : acc.y;
-        }
+        for (int k = 0; k < SLOTS; ++k) acc = acc + mk(fr[k].x, fr[k].y);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         tr_lap(3);
