@@ -417,7 +417,13 @@ int sort_despawn(PedoniModel* m)
         {
             Timed t(m, PEDONI_K_REORDER);
             if (t.rc) return t.rc;
-            hipLaunchKernelGGL(reorder_kernel, dim3(std::min(blocks_for(n_threads, bs), 1024u)), dim3(bs), 0,
+            // grid-stride kernel.  A steady-state tick has nothing (or, for a band, only the agents
+            // of its four boundary rows) in general form and every surplus block costs dispatch
+            // time (1024 blocks that leave after one flag read: 4.5 us), so the grid is small
+            // unless the host already knows the whole pass is in general form; a far mover found
+            // by the device alone is reordered by the small grid, correctly and slowly.
+            const uint32_t reorder_blocks = std::min(blocks_for(n_threads, bs), force_general ? 1024u : 128u);
+            hipLaunchKernelGGL(reorder_kernel, dim3(reorder_blocks), dim3(bs), 0,
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
                                m->d_cs[cs_new], m->d_slots, m->d_flags, parity, m->d_scan_in, soa);
         }
