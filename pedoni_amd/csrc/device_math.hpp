@@ -214,9 +214,16 @@ __device__ __forceinline__ MapDims dims_of(const FieldView& f)
 }
 constexpr uint32_t STATUS_FIELD_SLICE = 4u; // a texel outside the uploaded rows of the maps was asked for
 
+// A map pointer read from memory (potential_maps[dest]) is a FLAT pointer to the compiler: its
+// loads would be flat_load_dword -- never merged into wider loads, and counted on the LDS counter
+// as well as the vector-memory one.  Every map lives in global memory: say so.
+typedef const __attribute__((address_space(1))) float* MapPtr;
+__device__ __forceinline__ MapPtr as_map(const float* g) { return (MapPtr)g; }
+
 // util.rs:30-36 + :53-56: texel or 1e12 when the index is negative / out of shape
-__device__ __forceinline__ float texel(const float* g, const MapDims& m, int64_t x, int64_t y)
+__device__ __forceinline__ float texel(const float* g_, const MapDims& m, int64_t x, int64_t y)
 {
+    MapPtr g = as_map(g_);
     if (x < 0 || y < 0 || y >= m.rows || x >= m.cols) return 1e12f;
     if (y < m.y_lo || y >= m.y_hi) {                     // in the field, not in this band's slice
         atomicOr(m.status, STATUS_FIELD_SLICE);
@@ -226,8 +233,9 @@ __device__ __forceinline__ float texel(const float* g, const MapDims& m, int64_t
 }
 
 // util.rs:44-58
-__device__ __forceinline__ float bilinear(const float* g, const MapDims& m, float px, float py)
+__device__ __forceinline__ float bilinear(const float* g_, const MapDims& m, float px, float py)
 {
+    MapPtr g = as_map(g_);
     const int32_t cols = m.cols;
     float bx = __builtin_floorf(px), by = __builtin_floorf(py);
     float tx = px - bx, ty = py - by;
@@ -235,11 +243,11 @@ __device__ __forceinline__ float bilinear(const float* g, const MapDims& m, floa
     int64_t ix = f32_as_i32(bx), iy = f32_as_i32(by);
     float g00, g01, g10, g11;
     if (ix >= 0 && iy >= m.y_lo && ix + 1 < cols && iy + 1 < m.y_hi) {   // all four texels in bounds
-        const float* r0 = g + ((int64_t)iy * (int64_t)cols + ix);
+        MapPtr r0 = g + ((int64_t)iy * (int64_t)cols + ix);
         g00 = r0[0]; g01 = r0[1]; g10 = r0[cols]; g11 = r0[cols + 1];
     } else {
-        g00 = texel(g, m, ix, iy);     g01 = texel(g, m, ix + 1, iy);
-        g10 = texel(g, m, ix, iy + 1); g11 = texel(g, m, ix + 1, iy + 1);
+        g00 = texel(g_, m, ix, iy);     g01 = texel(g_, m, ix + 1, iy);
+        g10 = texel(g_, m, ix, iy + 1); g11 = texel(g_, m, ix + 1, iy + 1);
     }
     float y = 0.0f;
     y += sy * sx * g00;
@@ -292,9 +300,10 @@ __device__ __forceinline__ AxisTaps axis_taps(float p)
 }
 
 // u[r][c] = bilinear(g, p + (c - 1, r - 1)); returns false when the patch form does not apply
-__device__ __forceinline__ bool stencil_taps(const float* __restrict__ g, const MapDims& m, float px,
+__device__ __forceinline__ bool stencil_taps(const float* __restrict__ g_, const MapDims& m, float px,
                                              float py, float (&u)[3][3])
 {
+    MapPtr g = as_map(g_);
     const int32_t cols = m.cols;
     AxisTaps ax = axis_taps(px), ay = axis_taps(py);
     int64_t x0 = ax.i[0], y0 = ay.i[0];
@@ -302,7 +311,7 @@ __device__ __forceinline__ bool stencil_taps(const float* __restrict__ g, const 
         return false;
     float P[4][4];
     if (x0 >= 0 && y0 >= m.y_lo && x0 + 3 < cols && y0 + 3 < m.y_hi) {
-        const float* row = g + (y0 * (int64_t)cols + x0);
+        MapPtr row = g + (y0 * (int64_t)cols + x0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -313,7 +322,7 @@ __device__ __forceinline__ bool stencil_taps(const float* __restrict__ g, const 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) P[r][c] = texel(g, m, x0 + c, y0 + r);
+            for (int c = 0; c < 4; ++c) P[r][c] = texel(g_, m, x0 + c, y0 + r);
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise tools/profile_stalls.sh passes into profiles/TAG_stalls.json.
 
-    tools/stall_summary.py TAG gpurun_out/stalls_TAG
+    tools/stall_summary.py TAG gpurun_out/stalls_TAG [SUFFIX]     (SUFFIX: "stalls" by default; "mem" for
+                                                                    tools/profile_mem.sh -> profiles/TAG_mem.json)
 
 Per kernel: the average of every collected counter over its launches, plus derived shares of
 the wave lifetime (SQ_WAVE_CYCLES, quad-cycles summed over waves): issuing (ACTIVE_INST_ANY),
@@ -19,6 +20,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def main():
     tag, out_dir = sys.argv[1], sys.argv[2]
+    suffix = sys.argv[3] if len(sys.argv) > 3 else "stalls"
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{out_dir}/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -51,7 +53,7 @@ def main():
         if d.get("SQ_WAVES") and d.get("SQ_INSTS_VALU"):
             d["valu_insts_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
         res[k] = d
-    p = ROOT / "profiles" / f"{tag}_stalls.json"
+    p = ROOT / "profiles" / f"{tag}_{suffix}.json"
     p.write_text(json.dumps(res, indent=1, sort_keys=True))
     for k, d in res.items():
         if "force" in k:
