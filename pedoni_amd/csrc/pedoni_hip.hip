@@ -534,10 +534,10 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         // 6 candidate slots per lane and batch (12-byte queue entries: 18 KB LDS per block).  For
         // large crowds the 94-SGPR, 7-waves-per-SIMD build of the kernel (kernels.hpp
         // force_kernel_queue_s94): 96.2 us against 100.5 us at N = 1e6, exact mode; small crowds
-        // (few waves per SIMD anyway) keep the default build.  PEDONI_FORCE_SLOTS overrides:
+        // (few waves per SIMD anyway) run the default build with 8-slot batches.  PEDONI_FORCE_SLOTS overrides:
         // 4 / 5 (s94), 6, 8, 15 (5 slots, default SGPRs), 16 / 18 (s94 with 6 / 8 slots).
         int slots = m->force_slots;
-        if (slots == 0) slots = n >= 400000u ? 16 : 6;
+        if (slots == 0) slots = n >= 400000u ? 16 : 8;   // (small crowds: 8-slot batches, 2-3 % over 6: tools/slots_sweep.sh at N = 1e5 .. 2.5e5)
         if (m->d_trace && (size_t)grid.x * FORCE_WAVES <= TRACE_WAVES) slots = 96;
         switch (slots + (fast ? 100 : 0)) {
         case 4: hipLaunchKernelGGL((force_kernel_queue_s94<0, 4>), grid, block, 0, stream, a); break;
