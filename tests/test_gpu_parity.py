@@ -59,6 +59,24 @@ def test_device_div_sqrt_are_ieee(hip):
         assert bit_equal(abi.selftest_math(1, np.abs(a)), np.sqrt(np.abs(a))).all()
 
 
+def test_device_sqrt_every_significand(hip):
+    """sqrt_core (rsq + one residual step) against IEEE sqrt for EVERY float of [1, 4): both
+    exponent parities x all 2^23 significands.  Its operations scale exactly with powers of 4
+    inside its domain [2^-96, inf), so this is the whole domain up to scaling (the literal sweep of
+    all 1.9e9 floats: tools/microbench/sqrt_variants.hip, tools/exhaustive_sqrt.py); plus a
+    strided pass over every binade, the domain's edges and what lies outside (generic path)."""
+    from pedoni_amd import abi
+    x = np.arange(0x3F800000, 0x40800000, dtype=np.uint32).view(np.float32)
+    assert bit_equal(abi.selftest_math(1, x), np.sqrt(x)).all()
+    y = np.concatenate([np.arange(0, 0x7F800001, 997, dtype=np.uint32),
+                        np.arange(0x0F800000 - 64, 0x0F800000 + 64, dtype=np.uint32),
+                        np.arange(0x7F800000 - 64, 0x7F800000 + 2, dtype=np.uint32)]).view(np.float32)
+    with np.errstate(all="ignore"):
+        want = np.sqrt(y)
+    got = abi.selftest_math(1, y)
+    assert (bit_equal(got, want) | (np.isnan(got) & np.isnan(want))).all()
+
+
 def test_device_division_core_is_ieee_in_its_domain(hip):
     """pair_force_hot divides with the compiler's own Newton/residual arithmetic minus its
     rescaling wrap (device_math.hpp div_core): identical to IEEE division wherever the hot
