@@ -17,8 +17,14 @@ INCLUDE = ROOT / "include"
 # op costs about two plain ones (tools/microbench/valu_issue.hip: v_pk_fma_f32 4.4 cycles against
 # 2.6 for v_fma_f32 at 6 waves/SIMD) and the pairing adds register moves: the force kernel is 3 %
 # faster without it (tools/ab_flags.sh, round 2).  Same operations, same bits.
+# -amdgpu-sched-strategy=max-memory-clause: the scheduler groups the force kernel's gathers (6
+# candidate loads per batch, the stencils' texel rows) into clauses; with the memory pipeline a
+# co-limiter of that kernel that is worth 2-2.5 % of the tick in both math modes
+# (profiles/r02_ab_sched.txt: max-ilp 0, iterative-ilp -14 %, amdgpu-trackers -1 %).  Scheduling
+# only: same operations, same bits, same register counts.
 HIP_FLAGS = [
-    "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "--offload-arch=gfx950",
+    "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+    "-mllvm", "-amdgpu-sched-strategy=max-memory-clause", "--offload-arch=gfx950",
     "-shared", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-value",
 ]
 
