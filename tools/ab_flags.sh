@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of compiler flags for libpedoni_hip.so on a GPU box: builds variants into /tmp and runs
+# A/B of compiler flags (on top of the build's own) for libpedoni_hip.so on a GPU box: builds variants into /tmp and runs
 # bench.py (no CPU baseline) with each.   bash tools/ab_flags.sh TAG "flags A" "flags B" ...
 TAG=${1:?tag}; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/ab_$TAG; mkdir -p "$OUT"
-BASE="-O3 -std=c++17 -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -shared -fPIC -I$ROOT/include -I$ROOT/pedoni_amd/csrc -I/opt/rocm/include"
+BASE="-O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-memory-clause --offload-arch=gfx950 -shared -fPIC -I$ROOT/include -I$ROOT/pedoni_amd/csrc -I/opt/rocm/include"
 i=0
 for FLAGS in "" "$@"; do
     mkdir -p /tmp/ab_$i; cp $ROOT/pedoni_amd/lib/libpedoni_host.so /tmp/ab_$i/   # resolves its libpedoni_hip.so via $ORIGIN
