@@ -174,10 +174,16 @@ __device__ __forceinline__ v2 normalize_or_zero(v2 a)
 // loses a wave per SIMD and ~4 % -- so the explicit form stays).
 __device__ __forceinline__ int32_t f32_as_i32(float v)
 {
+#ifdef PEDONI_CVT_HW   // A/B switch (tools/ab_flags.sh "-DPEDONI_CVT_HW"): the bare instruction, see above
+    int32_t r;
+    asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#else
     if (v != v) return 0;
     if (v >= 2147483648.0f) return INT32_MAX;
     if (v <= -2147483648.0f) return INT32_MIN;
     return (int32_t)v;
+#endif
 }
 
 // ---- field sampling (util.rs:44-75, field.rs:235-258) -----------------------------
