@@ -307,6 +307,11 @@ int pedoni_hip_eikonal(int device, float* potential, const float* slowness, floa
  * bound of the arrays).  While it is non-zero every read of device state -- get_pedestrian_count,
  * download, list_pedestrians, owned_count -- fails with PEDONI_E_HIP / PEDONI_E_CAPACITY. */
 int pedoni_hip_debug_set_status(PedoniModel* m, uint32_t status_word);
+/* Diagnostics: the force kernel's ablation mask (what PEDONI_ABLATE sets at create): bit 0 no
+ * goal sampling, 1 no wall term, 2 no pairs, 3 phase 2 without its gather, 4 phase 2 without its
+ * arithmetic, 5 no despawn sampling, 6 no row counts, 7 no counts.  Timing only -- results are
+ * wrong while any bit is set (tools/ablate_launch.py). */
+int pedoni_hip_debug_set_ablate(PedoniModel* m, uint32_t bits);
 /* [ext] diagnostic: a model created under PEDONI_FORCE_TRACE=1 runs an instrumented build of the
  * force kernel (never the product kernel) whose waves add the shader cycles they spent in the
  * prologue, phases 1 / 2 / 3 and the epilogue (sums7[0..4]), their lifetimes ([5]) and their

@@ -39,7 +39,7 @@ SYMBOLS = [
     "pedoni_hip_halo_tick_begin", "pedoni_hip_halo_tick_end",
     "pedoni_hip_owned_count",
     "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_selftest_field", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
-    "pedoni_hip_debug_set_status", "pedoni_hip_debug_force_trace", "pedoni_hip_profile_every",
+    "pedoni_hip_debug_set_status", "pedoni_hip_debug_set_ablate", "pedoni_hip_debug_force_trace", "pedoni_hip_profile_every",
     "pedoni_hip_create_rows", "pedoni_shard_map_rows", "pedoni_hip_eikonal",
     "pedoni_shard_unique_id", "pedoni_shard_balanced_bounds", "pedoni_shard_recut_bounds", "pedoni_shard_create", "pedoni_shard_destroy",
     "pedoni_shard_begin", "pedoni_shard_tick_n", "pedoni_shard_owned_count", "pedoni_shard_band",
@@ -422,6 +422,10 @@ class HipModel:
     def debug_set_status(self, word: int) -> None:
         """Test hook: overwrite the sticky device status word (0 clears it)."""
         _check(self._lib, self._lib.pedoni_hip_debug_set_status(self._h, C.c_uint32(word)))
+
+    def debug_set_ablate(self, bits: int) -> None:
+        """Diagnostics: switch parts of the force kernel off (timing only, results wrong)."""
+        _check(self._lib, self._lib.pedoni_hip_debug_set_ablate(self._h, C.c_uint32(bits)))
 
 
 # -- multi-GPU driver below the C-ABI (pedoni_shard_*) ---------------------------------------

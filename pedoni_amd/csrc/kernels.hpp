@@ -99,6 +99,8 @@ constexpr uint32_t STATUS_LIVE_OVERFLOW = 2u; // more live agents than the host'
 __device__ __forceinline__ void count_key(uint32_t* __restrict__ cell_count, uint32_t* __restrict__ row_count,
                                           bool todo, uint32_t k, uint32_t cy)
 {
+    // (one atomic per agent.  Adding a run of equal keys -- neighbouring lanes, the agents being in
+    // cell order -- by its first lane, 0.44 atomics per agent, was built and verified: no faster)
     if (todo) atomicAdd(&cell_count[k], 1u);
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
@@ -537,7 +539,8 @@ struct ForceArgs {
     uint32_t parity_next;
     int32_t xcd_remap; // XCD-contiguous block order (PEDONI_NO_XCD_REMAP=1 turns it off)
     unsigned long long* trace; // TRACE build only (7 words, see force_queue_body)
-    int32_t ablate; // diagnostics only (PEDONI_ABLATE): 1 = no goal sampling, 2 = no obstacle term, 4 = no pairs
+    int32_t ablate; // diagnostics only (PEDONI_ABLATE): 1 = no goal sampling, 2 = no obstacle term, 4 = no pairs; in the
+                    // ablation build only: 8 / 16 = phase 2 without its gather / arithmetic, 32 = no despawn sampling, 64 / 128 = no row / no counts
 };
 
 // goal force, sfm.rs:106-109
@@ -706,7 +709,7 @@ constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 // shader cycles (s_memtime) it spent in the prologue, in phases 1 / 2 / 3 and in the epilogue to
 // its own record a.trace[8 * wave + 0..4], its lifetime to [5] and 1 to [6] -- where a wave's
 // WALL time goes, waiting and being passed over by the arbiter included.
-template <int MODE, int SLOTS, bool TRACE = false>
+template <int MODE, int SLOTS, bool TRACE = false, bool ABL = false>
 __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
 {
     unsigned long long tr_t0 = 0, tr_mark = 0, tr_acc[5] = {0, 0, 0, 0, 0};
@@ -860,15 +863,20 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
             const bool busy = q < qlen;
             const uint32_t w = busy ? who[q] : (id_safe | (lane << 26));
             // the neighbour's velocity and |v| * 0.1 (sfm.rs:140,144): one 16-byte load
+            // (PEDONI_ABLATE & 8, diagnostics: every lane reads the velocity record of ITS OWN agent --
+            // a coalesced, cached load in place of the gather; results wrong, arithmetic the same)
             const float4 vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.velx) +
-                                                               ((w & 0x03ffffffu) << 4));
+                                                               (((ABL && (a.ablate & 8)) ? id_safe : (w & 0x03ffffffu)) << 4));
             // the owner's goal direction, straight from its registers (every lane takes part)
             const int own = (int)(w >> 26);
             const float eo_x = __shfl(e.x, own, 64), eo_y = __shfl(e.y, own, 64);
             if (busy) {
                 float2 en = queue[q];
                 // the force itself (the owner's `acc += force` of sfm.rs:153 happens in phase 3)
-                const v2 f = pair_force_value<MODE>(mk(en.x, en.y), mk(eo_x, eo_y), mk(vn.x, vn.y), vn.z, tab);
+                // (PEDONI_ABLATE & 16, diagnostics: no pair arithmetic -- the loads, the queue and the
+                // ordered sums stay)
+                v2 f = mk(en.x + vn.x + eo_x, en.y + vn.y + eo_y + vn.z);
+                if (!(ABL && (a.ablate & 16))) f = pair_force_value<MODE>(mk(en.x, en.y), mk(eo_x, eo_y), mk(vn.x, vn.y), vn.z, tab);
                 queue[q] = make_float2(f.x, f.y);
             }
         }
@@ -934,16 +942,27 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         uint32_t k = DEAD;
         int32_t cx = 0, cy = 0;
         if (cell_xy(a.grid, pos, cx, cy) && cy >= a.band_lo - 1 && cy <= a.band_hi &&
-            survives(a.field, pos, a.dest[id])) {
+            ((ABL && (a.ablate & 32)) || survives(a.field, pos, a.dest[id]))) {
             {
                 k = (uint32_t)cy * (uint32_t)a.grid.cols + (uint32_t)cx;
                 if (abs(cx - ix) > 1 || abs(cy - iy) > 1) atomicOr(&a.flags->far[a.parity_next], 1u);
             }
         }
         a.key_next[id] = k;
-        count_key(a.cell_count, a.row_count, k != DEAD, k, (uint32_t)cy);
+        if (ABL && (a.ablate & 64)) { if (k != DEAD) atomicAdd(&a.cell_count[k], 1u); }     // (diagnostics: no row counts)
+        else if (ABL && (a.ablate & 128)) { if (k == 0xfffffffeu) atomicAdd(&a.cell_count[k], 1u); }   // (no counts at all)
+        else count_key(a.cell_count, a.row_count, k != DEAD, k, (uint32_t)cy);
     }
     tr_flush();
+}
+
+// diagnostic build of the 7-wave kernel with the extended ablation switches (PEDONI_ABLATE bits 8
+// and up; tools/ablate_launch.py): a build of its own, so that the product kernels carry none of it
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_ablate(ForceArgs a)
+{
+    force_queue_body<MODE, SLOTS, false, true>(a);
 }
 
 // diagnostic build of the 7-wave kernel with per-phase cycle accounting (see TRACE above)

@@ -539,6 +539,7 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         int slots = m->force_slots;
         if (slots == 0) slots = n >= 400000u ? 16 : 8;   // (small crowds: 8-slot batches, 2-3 % over 6: tools/slots_sweep.sh at N = 1e5 .. 2.5e5)
         if (m->d_trace && (size_t)grid.x * FORCE_WAVES <= TRACE_WAVES) slots = 96;
+        if (m->ablate & ~7) slots = 97;          // extended ablation switches: their own build
         switch (slots + (fast ? 100 : 0)) {
         case 4: hipLaunchKernelGGL((force_kernel_queue_s94<0, 4>), grid, block, 0, stream, a); break;
         case 5: hipLaunchKernelGGL((force_kernel_queue_s94<0, 5>), grid, block, 0, stream, a); break;
@@ -546,6 +547,8 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         case 16: hipLaunchKernelGGL((force_kernel_queue_s94<0, 6>), grid, block, 0, stream, a); break;
         case 18: hipLaunchKernelGGL((force_kernel_queue_s94<0, 8>), grid, block, 0, stream, a); break;
         case 96: hipLaunchKernelGGL((force_kernel_queue_trace<0, 6>), grid, block, 0, stream, a); break;
+        case 97: hipLaunchKernelGGL((force_kernel_queue_ablate<0, 6>), grid, block, 0, stream, a); break;
+        case 197: hipLaunchKernelGGL((force_kernel_queue_ablate<1, 6>), grid, block, 0, stream, a); break;
         case 196: hipLaunchKernelGGL((force_kernel_queue_trace<1, 6>), grid, block, 0, stream, a); break;
         case 116: hipLaunchKernelGGL((force_kernel_queue_s94<1, 6>), grid, block, 0, stream, a); break;
         case 8: hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, stream, a); break;
@@ -1502,6 +1505,16 @@ int pedoni_hip_debug_set_status(PedoniModel* m, uint32_t status_word)
     TRY(bind(m));
     HIP_TRY(hipMemcpyAsync(m->d_live + 1, &status_word, sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    return PEDONI_OK;
+}
+
+// diagnostics: the PEDONI_ABLATE bit mask of the force kernel (timing only, results wrong), settable
+// between ticks so that ONE launch of a warmed-up crowd can be timed with parts switched off
+int pedoni_hip_debug_set_ablate(PedoniModel* m, uint32_t bits)
+{
+    TRY(bind(m));
+    m->ablate = (int)bits;
+    m->graph_valid = false;
     return PEDONI_OK;
 }
 
