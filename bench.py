@@ -377,7 +377,8 @@ def main() -> None:
         use_overlap = mode_ms[True] < mode_ms[False]
         shard.set_overlap(use_overlap)
         exchange += (f"; tick form: {'overlapped' if use_overlap else 'plain'} "
-                     f"(probe: plain {mode_ms[False] * 1e3:.0f} us, overlapped {mode_ms[True] * 1e3:.0f} us per tick)")
+                     f"(probe: plain {mode_ms[False] * 1e3:.0f} us, overlapped {mode_ms[True] * 1e3:.0f} us per tick; "
+                     "its 50 ticks precede the warmup, so the timed crowd is 50 ticks older than a 1-GPU run's)")
     elif runner is not None:
         assert (runner.owner_of(pos[:, 1]) == rank).all()
         runner.load(pos, dest, v0, vel)
