@@ -138,12 +138,18 @@ def cpu_baseline(size, field, obstacles, pos, dest, v0, vel, budget_s: float = 2
     }
 
 
+def _by_age(path):
+    """Sort key of profiles/rNN_vM_* names: numeric fields compare as numbers (v11 after v9)."""
+    import re
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", path.name)]
+
+
 def pmc_traffic(workload: str):
     """HBM bytes per force-kernel launch from the newest committed rocprofv3 --pmc passes
     (profiles/*pmc_force*.json written by tools/pmc_summary.py) for this workload, with the
     profile it came from -- (bytes, tag) or (None, None)."""
     best = (None, None)
-    for p in sorted((ROOT / "profiles").glob("*pmc_force*.json")):      # rNN_vM names sort by age
+    for p in sorted((ROOT / "profiles").glob("*pmc_force*.json"), key=_by_age):      # rNN_vM names, oldest first
         try:
             d = json.loads(p.read_text())
         except Exception:
@@ -168,7 +174,7 @@ def valu_floor(avg_launch_ms: float):
     cycles per launch / the profiled launch duration)."""
     best = None
     names = sorted((ROOT / "profiles").glob("*_stalls.json"),
-                   key=lambda q: (0 if "_base_" in q.name else 1, q.name))                 # rNN_vM names sort by age
+                   key=lambda q: (0 if "_base_" in q.name else 1, _by_age(q)))             # rNN_vM names, oldest first
     for p in names:
         try:
             d = json.loads(p.read_text())
