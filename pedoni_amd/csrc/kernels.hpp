@@ -433,6 +433,13 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
     if (c == DEAD) return;
     uint32_t cy = c / (uint32_t)grid.cols, cx = c - cy * (uint32_t)grid.cols;
     if (!general_cell(flags, parity, band, (int32_t)cy)) {
+        // the agent's own record and its cell's start depend on j and c alone: requested BEFORE the
+        // rank scan, they arrive while it runs (a latency-bound kernel: one dependent stretch less
+        // per wave, 21 -> 19 us)
+        const float2 p_in = a.pos_in[j];
+        float4 v_in = a.velx_in[j];
+        const uint32_t d_in = a.dest_in[j];
+        const uint32_t start = cs_new[c];
         CellRanges r = old_ranges(cs_old, grid, (int32_t)cx, (int32_t)cy);
         uint32_t before = 0;
 #pragma unroll
@@ -440,11 +447,16 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
             const uint32_t hi = min(r.hi[k], j);
             for (uint32_t i = r.lo[k]; i < hi; ++i) before += key[i] == c ? 1u : 0u;
         }
-        const uint32_t to = cs_new[c] + before;
-        // (never taken unless the live count exceeds the host's bound: scan_rows_kernel has
-        // raised STATUS_LIVE_OVERFLOW then; do not write past the arrays)
-        if (to < n_total) move_agent(a, j, to, pack_cell(cx, cy));
-        else atomicOr(status, STATUS_LIVE_OVERFLOW);
+        const uint32_t to = start + before;
+        // (`to >= n_total` is never taken unless the live count exceeds the host's bound:
+        // scan_rows_kernel has raised STATUS_LIVE_OVERFLOW then; do not write past the arrays)
+        if (to < n_total) {                                      // = move_agent(a, j, to, ..)
+            a.pos_out[to] = p_in;
+            v_in.z = a.fast ? neighbour_vl<1>(mk(v_in.x, v_in.y)) : neighbour_vl<0>(mk(v_in.x, v_in.y));
+            a.velx_out[to] = v_in;
+            a.dest_out[to] = d_in;
+            a.skey_out[to] = pack_cell(cx, cy);
+        } else atomicOr(status, STATUS_LIVE_OVERFLOW);
     } else {
         const uint32_t to = cs_new[c] + atomicAdd(&cell_count[c], 1u);
         if (to < n_total) slots[to] = j;
