@@ -929,6 +929,14 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         return;
     }
 
+    // (the despawn test's destination and map pointer, requested here so that they travel beside the
+    // wall texels instead of forming two dependent stretches of their own after the integrator)
+    uint32_t dest_k = 0;
+    const float* map_k = nullptr;
+    if (a.key_next) {
+        dest_k = a.dest[id];
+        map_k = dest_k < a.field.n_maps ? a.field.potential_maps[dest_k] : nullptr;
+    }
     if (a.ablate & 2) {}
     else if (a.use_distance_map) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
     else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
@@ -953,8 +961,9 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
     if (a.key_next) {
         uint32_t k = DEAD;
         int32_t cx = 0, cy = 0;
+        const v2 qk = field_coord(a.field, pos);                 // = survives(a.field, pos, dest_k)
         if (cell_xy(a.grid, pos, cx, cy) && cy >= a.band_lo - 1 && cy <= a.band_hi &&
-            ((ABL && (a.ablate & 32)) || survives(a.field, pos, a.dest[id]))) {
+            ((ABL && (a.ablate & 32)) || (map_k && bilinear(map_k, dims_of(a.field), qk.x, qk.y) > 0.25f))) {
             {
                 k = (uint32_t)cy * (uint32_t)a.grid.cols + (uint32_t)cx;
                 if (abs(cx - ix) > 1 || abs(cy - iy) > 1) atomicOr(&a.flags->far[a.parity_next], 1u);
