@@ -305,3 +305,20 @@ def test_upstream_test_obstacle_shape_printed_grid(oracle):
     grid = ["".join("#" if c else "." for c in row) for row in mask]
     assert grid == expected, "\n" + "\n".join(grid)
     assert np.array_equal(_exact_traversal(verts, 10, 20), mask)
+
+
+def test_bench_picks_the_newest_committed_profile():
+    """bench.py labels its roofline with the newest profiles/rNN_vM_* files: versions compare as numbers."""
+    from pathlib import Path
+    import bench
+    names = ["r02_v9_stalls.json", "r02_v11_stalls.json", "r01_v6_stalls.json", "r02_v10_stalls.json", "r10_v1_stalls.json"]
+    ordered = sorted((Path(n) for n in names), key=bench._by_age)
+    assert [p.name for p in ordered] == ["r01_v6_stalls.json", "r02_v9_stalls.json", "r02_v10_stalls.json",
+                                         "r02_v11_stalls.json", "r10_v1_stalls.json"]
+    traffic, tag = bench.pmc_traffic("uniform crowd N=1e6 (1e6/GPU) in a 1000x1000 m box, rho=1/m^2, neighbor grid 1.4 m, "
+                                     "field maps 0.25 m, fp32")
+    newest = sorted(Path(bench.ROOT / "profiles").glob("*pmc_force*.json"), key=bench._by_age)[-1].name
+    assert tag == newest and traffic > 0
+    floor = bench.valu_floor(0.09)
+    assert floor and floor["profile"] == sorted(Path(bench.ROOT / "profiles").glob("r*_v*_stalls.json"),
+                                                key=bench._by_age)[-1].name
