@@ -109,11 +109,29 @@ def build_oracle(force: bool = False) -> Path:
     return out
 
 
+def build_loopback(force: bool = False, verbose: bool = False) -> Path:
+    """tests/loopback_rccl: an in-process stand-in for RCCL's send / receive, so that the
+    multi-rank driver runs with world > 1 on one GPU.  Test infrastructure like the oracle:
+    only the tests load it (PEDONI_RCCL_LIB), never the product by itself."""
+    ldir = ROOT / "tests" / "loopback_rccl"
+    src, out = ldir / "loopback_rccl.cpp", ldir / "libloopback_rccl.so"
+    if not force and _newer(out, [src]):
+        return out
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-result",
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", str(out), str(src), "-L/opt/rocm/lib",
+           "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-pthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_hip(force, verbose)
     build_host(force, verbose)
     build_cli(force, verbose)
     build_oracle(force)
+    build_loopback(force, verbose)
 
 
 if __name__ == "__main__":

@@ -76,8 +76,11 @@ struct EventPair {
 
 } // namespace
 
+struct PedoniShard;
+
 struct PedoniModel {
     int device = 0;
+    PedoniShard* shard = nullptr;           // the shard driving this model, if any (shard.hpp)
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t side_stream = nullptr;      // interior rows of a split sharded tick
     hipEvent_t ev_sorted = nullptr, ev_interior = nullptr;
@@ -170,6 +173,8 @@ struct PedoniModel {
     size_t ev_used = 0;
     PedoniKernelTimes times{};
 };
+
+void shard_detach_model(PedoniModel* m);   // shard.hpp
 
 namespace {
 
@@ -864,6 +869,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     if (!m) return;
     hipSetDevice(m->device);
     if (m->stream) hipStreamSynchronize(m->stream);
+    shard_detach_model(m);      // a shard that outlives its model fails with "null shard" from now on
     for (auto& p : m->ev_pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (int k = 0; k < 2; ++k) {
         hipFree(m->d_pos[k]); hipFree(m->d_velx[k]); hipFree(m->d_dest[k]);
@@ -1048,6 +1054,7 @@ int pedoni_hip_set_spawners(PedoniModel* m, const PedoniSpawner* spawners, uint3
         return fail(PEDONI_E_INVALID, "set_spawners: device spawning needs the neighbor grid "
                                       "(the brute-force option path spawns on the host)");
     HIP_TRY(hipStreamSynchronize(m->stream));
+    m->graph_valid = false;
     if (m->n_spawners) { // hand the desired-speed stream back to the host side
         SpawnState st{};
         HIP_TRY(hipMemcpy(&st, m->d_spawn_state, sizeof st, hipMemcpyDeviceToHost));
@@ -1215,6 +1222,7 @@ int pedoni_hip_clear(PedoniModel* m)
     m->have_old = false;
     m->keys_valid = false;
     m->sorted = false;
+    m->graph_valid = false;       // the captured tick pair bakes in band, bounds and buffers
     return PEDONI_OK;
 }
 
@@ -1266,6 +1274,7 @@ int pedoni_hip_set_stream(PedoniModel* m, void* hip_stream, int32_t use_library_
     TRY(drain_events(m));
     HIP_TRY(hipStreamSynchronize(m->stream));
     m->stream = use_library_stream ? m->own_stream : (hipStream_t)hip_stream;
+    m->graph_valid = false;
     return PEDONI_OK;
 }
 
@@ -1323,6 +1332,7 @@ int pedoni_hip_set_band(PedoniModel* m, int32_t row_begin, int32_t row_end, uint
     m->band_hi = row_end;
     m->halo_cap = halo_cap;
     m->base = halo_cap;
+    m->graph_valid = false;       // (band_lo / band_hi are arguments of the captured kernels)
     TRY(ensure_capacity(m, m->base + std::max<uint32_t>(m->opt.initial_capacity, 1024)));
     return pedoni_hip_clear(m);
 }

@@ -22,6 +22,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <mutex>
+
+#include "rccl_group.hpp"
+
 namespace {
 
 struct RcclApi {
@@ -38,44 +42,70 @@ struct RcclApi {
     std::string error;
 };
 
+// One-time resolution (std::call_once: the models are driven from several host threads).
+// PEDONI_RCCL_LIB names the library instead of the default search list (a site's own build of
+// RCCL; the in-process loop-back transport of tests/loopback_rccl; a path that does not exist
+// exercises the "RCCL absent" branch).
 RcclApi& rccl()
 {
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return api;
-    tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (api.handle) break;
-    }
-    if (!api.handle) {
-        api.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
-        return api;
-    }
-    auto sym = [&](const char* n) -> void* {
-        void* p = dlsym(api.handle, n);
-        if (!p && api.error.empty()) api.error = std::string("librccl lacks ") + n;
-        return p;
-    };
-    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
-    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
-    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
-    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
-    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
-    api.Send = (decltype(api.Send))sym("ncclSend");
-    api.Recv = (decltype(api.Recv))sym("ncclRecv");
-    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
-    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::vector<std::string> names;
+        if (const char* over = std::getenv("PEDONI_RCCL_LIB"); over && *over) names.emplace_back(over);
+        else names = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        std::string last = "?";
+        for (const std::string& name : names) {
+            api.handle = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
+            if (api.handle) break;
+            const char* e = dlerror();           // (read ONCE: dlerror() clears the message it returns)
+            if (e) last = e;
+        }
+        if (!api.handle) {
+            api.error = "librccl not found: " + last;
+            return;
+        }
+        auto sym = [&](const char* n) -> void* {
+            void* p = dlsym(api.handle, n);
+            if (!p && api.error.empty()) api.error = std::string("librccl lacks ") + n;
+            return p;
+        };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.Send = (decltype(api.Send))sym("ncclSend");
+        api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    });
     return api;
+}
+
+std::string rccl_error(const char* what, ncclResult_t r)
+{
+    return std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r) : "rccl error");
 }
 
 #define NCCL_TRY(expr)                                                                       \
     do {                                                                                     \
         ncclResult_t r_ = (expr);                                                            \
-        if (r_ != ncclSuccess)                                                               \
-            return fail(PEDONI_E_HIP, std::string(#expr) + ": " +                            \
-                                          (rccl().GetErrorString ? rccl().GetErrorString(r_) : "rccl error")); \
+        if (r_ != ncclSuccess) return fail(PEDONI_E_HIP, rccl_error(#expr, r_));             \
     } while (0)
+
+// One grouped exchange.  `body(op)` issues the sends / receives through op(call, what); after the
+// first failure the remaining calls are skipped, but ncclGroupEnd is ALWAYS called: a rank that
+// returned from inside an open group would leave it open for every later call on this thread
+// while its peers wait in theirs (rccl_group.hpp has the logic, tested on the CPU with a mock).
+template <typename Body> int rccl_group(const char* what, Body&& body)
+{
+    RcclApi& api = rccl();
+    const GroupOutcome<ncclResult_t> o = run_group<ncclResult_t>(
+        ncclSuccess, [&] { return api.GroupStart(); }, [&] { return api.GroupEnd(); }, body);
+    if (o.ok) return PEDONI_OK;
+    return fail(PEDONI_E_HIP, std::string(what) + ": " + rccl_error(o.where, o.code));
+}
 
 // ---- device side of the re-cut ---------------------------------------------------------------
 // agents per OWNED grid row (zero elsewhere), read off cell_start
@@ -168,8 +198,10 @@ struct PedoniShard {
     bool lists_ready = false;   // the receive buffers already hold this tick's lists
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_recv = nullptr;
-    // members of a local group (one process, one device) reach each other directly
+    // members of a local group (one process, one device) reach each other directly -- through the
+    // caller's array, valid only inside pedoni_shard_local_group_tick_n
     PedoniShard** group = nullptr;
+    bool local_member = false;        // has ticked as a member of a local group
     // initial bounds and slack every rank's map slice was cut with (pedoni_shard_map_rows): a
     // re-cut may move boundary b only where both adjoining bands still fit their slices
     std::vector<int32_t> bounds0;
@@ -195,17 +227,16 @@ int shard_exchange_rccl(PedoniShard* s, hipStream_t st)
     if (!s->comm) return fail(PEDONI_E_INVALID, "shard has no communicator (created without an id)");
     RcclApi& api = rccl();
     const size_t n = s->words_each;
-    NCCL_TRY(api.GroupStart());
-    if (s->rank > 0) {
-        NCCL_TRY(api.Send(s->d_send, n, ncclUint32, s->rank - 1, s->comm, st));           // my DOWN list
-        NCCL_TRY(api.Recv(s->d_recv_below + n, n, ncclUint32, s->rank - 1, s->comm, st)); // its UP list
-    }
-    if (s->rank + 1 < s->world) {
-        NCCL_TRY(api.Send(s->d_send + n, n, ncclUint32, s->rank + 1, s->comm, st));       // my UP list
-        NCCL_TRY(api.Recv(s->d_recv_above, n, ncclUint32, s->rank + 1, s->comm, st));     // its DOWN list
-    }
-    NCCL_TRY(api.GroupEnd());
-    return PEDONI_OK;
+    return rccl_group("halo exchange", [&](auto&& op) {
+        if (s->rank > 0) {
+            op([&] { return api.Send(s->d_send, n, ncclUint32, s->rank - 1, s->comm, st); }, "ncclSend(down list)");
+            op([&] { return api.Recv(s->d_recv_below + n, n, ncclUint32, s->rank - 1, s->comm, st); }, "ncclRecv(up list of the band below)");
+        }
+        if (s->rank + 1 < s->world) {
+            op([&] { return api.Send(s->d_send + n, n, ncclUint32, s->rank + 1, s->comm, st); }, "ncclSend(up list)");
+            op([&] { return api.Recv(s->d_recv_above, n, ncclUint32, s->rank + 1, s->comm, st); }, "ncclRecv(down list of the band above)");
+        }
+    });
 }
 
 int shard_exchange_local(PedoniShard* s)
@@ -266,17 +297,16 @@ int recut_exchange_rccl(PedoniShard* s)
 {
     RcclApi& api = rccl();
     hipStream_t st = s->m->stream;
-    NCCL_TRY(api.GroupStart());
-    if (s->rank > 0) {
-        NCCL_TRY(api.Send(s->d_bulk_send[0], s->bulk_words, ncclUint32, s->rank - 1, s->comm, st));
-        NCCL_TRY(api.Recv(s->d_bulk_recv[0], s->bulk_words, ncclUint32, s->rank - 1, s->comm, st));
-    }
-    if (s->rank + 1 < s->world) {
-        NCCL_TRY(api.Send(s->d_bulk_send[1], s->bulk_words, ncclUint32, s->rank + 1, s->comm, st));
-        NCCL_TRY(api.Recv(s->d_bulk_recv[1], s->bulk_words, ncclUint32, s->rank + 1, s->comm, st));
-    }
-    NCCL_TRY(api.GroupEnd());
-    return PEDONI_OK;
+    return rccl_group("re-cut exchange", [&](auto&& op) {
+        if (s->rank > 0) {
+            op([&] { return api.Send(s->d_bulk_send[0], s->bulk_words, ncclUint32, s->rank - 1, s->comm, st); }, "ncclSend(rows down)");
+            op([&] { return api.Recv(s->d_bulk_recv[0], s->bulk_words, ncclUint32, s->rank - 1, s->comm, st); }, "ncclRecv(rows from below)");
+        }
+        if (s->rank + 1 < s->world) {
+            op([&] { return api.Send(s->d_bulk_send[1], s->bulk_words, ncclUint32, s->rank + 1, s->comm, st); }, "ncclSend(rows up)");
+            op([&] { return api.Recv(s->d_bulk_recv[1], s->bulk_words, ncclUint32, s->rank + 1, s->comm, st); }, "ncclRecv(rows from above)");
+        }
+    });
 }
 
 int recut_exchange_local(PedoniShard* s)
@@ -401,6 +431,12 @@ int shard_tick_rccl(PedoniShard* s)
 
 } // namespace
 
+void shard_detach_model(PedoniModel* m)
+{
+    if (m->shard) m->shard->m = nullptr;
+    m->shard = nullptr;
+}
+
 extern "C" {
 
 int pedoni_shard_unique_id(uint8_t id[PEDONI_SHARD_ID_BYTES])
@@ -502,8 +538,10 @@ int pedoni_shard_create(PedoniModel* m, int32_t rank, int32_t world, const uint8
     for (int32_t r = 0; r < world; ++r)
         if (row_bounds[r + 1] - row_bounds[r] < 2 || row_bounds[0] != 0 || row_bounds[world] != m->grid.rows)
             return fail(PEDONI_E_INVALID, "shard_create: row_bounds must rise from 0 to the grid's rows, >= 2 rows per band");
+    if (m->shard) return fail(PEDONI_E_INVALID, "shard_create: the model already belongs to a shard");
     PedoniShard* s = new PedoniShard();
     s->m = m;
+    m->shard = s;      // pedoni_hip_destroy(m) before pedoni_shard_destroy(s) detaches instead of dangling
     s->rank = rank;
     s->world = world;
     s->bounds.assign(row_bounds, row_bounds + world + 1);
@@ -539,6 +577,7 @@ void pedoni_shard_destroy(PedoniShard* s)
     if (s->m) {
         hipSetDevice(s->m->device);
         if (s->m->stream) hipStreamSynchronize(s->m->stream);
+        s->m->shard = nullptr;
     }
     if (s->comm_stream) { hipStreamSynchronize(s->comm_stream); hipStreamDestroy(s->comm_stream); }
     if (s->ev_packed) hipEventDestroy(s->ev_packed);
@@ -563,7 +602,7 @@ int pedoni_shard_tick_n(PedoniShard* s, uint32_t steps)
 {
     TRY(shard_check(s));
     if (!s->begun) return fail(PEDONI_E_INVALID, "shard_tick_n: call pedoni_shard_begin after loading the band");
-    if (s->group) return fail(PEDONI_E_INVALID, "shard_tick_n: a member of a local group ticks with pedoni_shard_local_group_tick_n");
+    if (s->local_member) return fail(PEDONI_E_INVALID, "shard_tick_n: a member of a local group ticks with pedoni_shard_local_group_tick_n");
     for (uint32_t k = 0; k < steps; ++k) TRY(shard_tick_rccl(s));
     return PEDONI_OK;
 }
@@ -629,7 +668,7 @@ int pedoni_shard_set_rebalance(PedoniShard* s, uint32_t every_ticks, uint32_t ma
 int pedoni_shard_set_overlap(PedoniShard* s, int32_t on)
 {
     TRY(shard_check(s));
-    if (s->group) return fail(PEDONI_E_INVALID, "set_overlap: not for members of a local group");
+    if (s->local_member) return fail(PEDONI_E_INVALID, "set_overlap: not for members of a local group");
     if (s->in_flight) {                                   // settle the exchange that is under way
         HIP_TRY(hipStreamWaitEvent(s->m->stream, s->ev_recv, 0));
         HIP_TRY(hipStreamSynchronize(s->m->stream));
@@ -656,10 +695,10 @@ int pedoni_shard_selftest(PedoniShard* s)
         const uint32_t token = 0x5E1F0001u;
         uint32_t got = 0;
         HIP_TRY(hipMemcpyAsync(s->d_send, &token, sizeof token, hipMemcpyHostToDevice, s->m->stream));
-        NCCL_TRY(api.GroupStart());
-        NCCL_TRY(api.Send(s->d_send, 1, ncclUint32, 0, s->comm, s->m->stream));
-        NCCL_TRY(api.Recv(s->d_recv_above, 1, ncclUint32, 0, s->comm, s->m->stream));
-        NCCL_TRY(api.GroupEnd());
+        TRY(rccl_group("self-addressed token", [&](auto&& op) {
+            op([&] { return api.Send(s->d_send, 1, ncclUint32, 0, s->comm, s->m->stream); }, "ncclSend");
+            op([&] { return api.Recv(s->d_recv_above, 1, ncclUint32, 0, s->comm, s->m->stream); }, "ncclRecv");
+        }));
         HIP_TRY(hipMemcpyAsync(&got, s->d_recv_above, sizeof got, hipMemcpyDeviceToHost, s->m->stream));
         HIP_TRY(hipStreamSynchronize(s->m->stream));
         HIP_TRY(hipMemsetAsync(s->d_send, 0, sizeof token, s->m->stream));
@@ -703,8 +742,14 @@ int pedoni_shard_local_group_tick_n(PedoniShard** shards, uint32_t n_shards, uin
             s->rebalance_every != shards[0]->rebalance_every || s->bulk_cap != shards[0]->bulk_cap)
             return fail(PEDONI_E_INVALID, "local group: shards must be ranks 0..n-1 of one world, begun, without a "
                                           "communicator, on ONE stream, with equal bounds and re-cut settings");
-        s->group = shards;
     }
+    // the members reach each other through the caller's array only while this call runs (the
+    // array may be a temporary of the caller's); `local_member` keeps them off pedoni_shard_tick_n
+    struct Membership {
+        PedoniShard** v; uint32_t n;
+        Membership(PedoniShard** v_, uint32_t n_) : v(v_), n(n_) { for (uint32_t r = 0; r < n; ++r) { v[r]->group = v; v[r]->local_member = true; } }
+        ~Membership() { for (uint32_t r = 0; r < n; ++r) v[r]->group = nullptr; }
+    } membership(shards, n_shards);
     for (uint32_t k = 0; k < steps; ++k) {
         for (uint32_t r = 0; r < n_shards; ++r) { TRY(shard_check(shards[r])); TRY(shard_exchange_local(shards[r])); }
         if (!recut_due(shards[0])) {

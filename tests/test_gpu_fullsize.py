@@ -170,6 +170,107 @@ def test_fast_math_dense_crowd_rho6_within_1e5(hip, oracle):
     assert worst <= 1e-5
 
 
+@functools.lru_cache(maxsize=None)
+def _c5_field():
+    """The C5 box (1000 x 8000 m, maps at 0.25 m: 3 x 512 MB), built once for both C5 tests."""
+    import bench
+    from pedoni_amd import host
+    obs, wps = bench.box_geometry(1000.0, 8000.0)
+    return obs, wps, host.Field.build((1000.0, 8000.0), 0.25, obs, wps)
+
+
+def test_c5_8e6_agents_through_the_shard_driver(hip, oracle):
+    """C5 on the driver that ships: the 8 bands are 8 `pedoni_shard_*` shards
+    ticked by pedoni_shard_local_group_tick_n -- the C-ABI driver `bench.py --gpus N` runs, with
+    its exchange done by device copies -- each holding only ITS texel rows of the field maps
+    (pedoni_hip_create_rows), cut by AGENT count (pedoni_shard_balanced_bounds, then pushed 3 rows
+    off so the re-cut has work), re-cut every 2 ticks.  The crowd is denser towards the middle of
+    the field, drifts vertically (agents cross every band edge every tick) and the merged bands
+    must equal the ORACLE's single 8e6-agent model bit for bit after 5 ticks."""
+    import torch
+    import bench
+    from pedoni_amd import abi
+
+    G, n_total, ticks, cap, slack = 8, 8_000_000, 5, 8192, 10
+    W, H = 1000.0, 8000.0
+    obs, wps, field = _c5_field()
+    rng = np.random.default_rng(2024)
+    pos, dest, v0, vel = bench.uniform_crowd(n_total, (12.0, W - 12.0), (2.0, H - 2.0), 777)
+    # density 1 +- 0.35 along y (inverse-CDF of 1 + 0.35 cos), so equal ROWS would not be equal AGENTS
+    u = (pos[:, 1].astype(np.float64) - 2.0) / (H - 4.0)
+    y = u.copy()
+    for _ in range(30):                                    # solve y + 0.35 sin(2 pi y) / (2 pi) = u
+        y = u - 0.35 * np.sin(2 * np.pi * y) / (2 * np.pi)
+    pos[:, 1] = (2.0 + y * (H - 4.0)).astype(np.float32)
+    vel[:, 1] = np.where(rng.random(n_total) < 0.5, 1.1, -1.1).astype(np.float32)
+
+    ofield = oracle.Field(field.unit, field.distance_map, field.potential_maps)
+    cpu = oracle.OracleModel((W, H))
+    cpu.spawn_pedestrians(ofield, pos, dest, v0, vel)
+    wp0 = cpu.download()[0]
+    rows = int(np.ceil(np.float32(H) / np.float32(1.4)))
+    row_of = lambda yy: np.trunc(yy / np.float32(1.4)).astype(np.int64)
+    row_counts = np.bincount(row_of(wp0[:, 1]), minlength=rows).astype(np.uint32)
+    ideal = abi.balanced_bounds(row_counts, G)
+    bounds = [ideal[0]] + [b + (3 if k % 2 else -3) for k, b in enumerate(ideal[1:-1])] + [ideal[-1]]
+    assert max(np.diff(ideal)) > 1.15 * min(np.diff(ideal)), "the crowd is not lopsided enough to matter"
+
+    stream = torch.cuda.current_stream().cuda_stream
+    models, shards = [], []
+    band_of = np.searchsorted(np.asarray(bounds[1:-1]), row_of(pos[:, 1]), side="right")
+    for r in range(G):
+        rows_needed = abi.shard_map_rows(bounds[r], bounds[r + 1], slack, 1.4, field.unit, field.shape[0])
+        assert rows_needed[1] - rows_needed[0] < field.shape[0] // 5      # a slice, not the whole 512 MB map
+        m = hip.HipModel(hip.Options(initial_capacity=int(n_total / G * 1.3)), (W, H), field.distance_map,
+                         field.potential_maps, field.unit, obs, map_rows=rows_needed)
+        m.set_stream(stream)
+        s = abi.Shard(m, r, G, bounds, cap)
+        s.set_rebalance(2, 3, map_slack_rows=slack)
+        sel = band_of == r
+        m.append(pos[sel], dest[sel], v0[sel], vel[sel])
+        s.begin()
+        models.append(m); shards.append(s)
+    assert sum(s.owned_count() for s in shards) == len(wp0)
+
+    crossed = 0
+    for t in range(ticks):
+        y0 = cpu.download()[0][:, 1]
+        cpu.update_states(ofield, obs)
+        y1 = cpu.download()[0][:, 1]
+        b_now = np.asarray(bounds[1:-1])
+        crossed += int((np.searchsorted(b_now, row_of(y0), side="right") !=
+                        np.searchsorted(b_now, row_of(y1), side="right")).sum())
+        cpu.spawn_pedestrians(ofield)
+    abi.local_group_tick_n(shards, ticks)
+    # bands: sort (exchange sort update pack)^T = the oracle's state one sort short: a last
+    # exchange + sort (no update) through the public halo entry points lines them up
+    words = hip.HipModel.halo_bytes(cap) // 4
+    sends = [torch.zeros(words, dtype=torch.int32, device="cuda") for _ in range(G)]
+    for m, snd in zip(models, sends):
+        m.halo_pack(snd.data_ptr(), cap)
+    for r, m in enumerate(models):
+        m.halo_unpack(sends[r - 1].data_ptr() if r > 0 else None, sends[r + 1].data_ptr() if r + 1 < G else None, cap)
+        m.sort_despawn()
+    torch.cuda.synchronize()
+
+    wp, wd, wv, w0 = cpu.download()
+    got_parts = [s.download_owned() for s in shards]
+    gp, gd, gv, g0 = (np.concatenate([p[k] for p in got_parts]) for k in range(4))
+    assert sum(s.owned_count() for s in shards) == len(wp) == len(gp)
+    assert n_total - 2000 < len(wp) <= n_total
+    assert np.array_equal(gd, wd)
+    assert bit_equal(gp, wp).all() and bit_equal(gv, wv).all() and bit_equal(g0, w0).all()
+    new_bounds = [shards[r].band()[0] for r in range(G)] + [shards[-1].band()[1]]
+    assert new_bounds != bounds, "the bands were never re-cut"
+    # the re-cut moved every boundary back towards the balanced cut
+    assert sum(abs(a - b) for a, b in zip(new_bounds, ideal)) < sum(abs(a - b) for a, b in zip(bounds, ideal))
+    assert crossed > 5000, f"only {crossed} agents changed bands: the exchange was not exercised"
+    for s in shards:
+        s.close()
+    for m in models:
+        m.close()
+
+
 def test_c5_8e6_agents_8_bands(hip, oracle):
     """BASELINE.json configs[4] (C5): 8e6 agents in a 1000 x 8000 m box cut into 8 row bands.
     No 8-GPU node is available to the suite, so the 8 bands are 8 models on ONE device and the
@@ -184,8 +285,7 @@ def test_c5_8e6_agents_8_bands(hip, oracle):
 
     G, n_per, ticks = 8, 1_000_000, 3
     W, H = 1000.0, 1000.0 * G
-    obs, wps = bench.box_geometry(W, H)
-    field = host.Field.build((W, H), 0.25, obs, wps)
+    obs, wps, field = _c5_field()
     parts = []
     for r in range(G):
         # no gap at the band edges (only the outer walls keep their 2 m): the boundary rows are populated

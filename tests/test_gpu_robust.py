@@ -182,3 +182,27 @@ def test_exchange_with_pending_appends_is_rejected(hip, oracle):
     with pytest.raises(abi.PedoniError, match="null send"):
         m.halo_tick(None, None, None, cap)
     m.close()
+
+
+def test_captured_tick_is_dropped_when_a_baked_in_argument_changes(hip, oracle, monkeypatch):
+    """the captured tick pair bakes in the band (kernel arguments), and its key held only
+    bounds / buffer indices.  clear + set_band (halo_cap 0) + the same number of agents used to
+    replay the OLD band.  Graph run == eager run (PEDONI_NO_GRAPH=1) through that sequence."""
+    def run(no_graph):
+        if no_graph:
+            monkeypatch.setenv("PEDONI_NO_GRAPH", "1")
+        else:
+            monkeypatch.delenv("PEDONI_NO_GRAPH", raising=False)
+        _, _, m, (pos, dest, v0, vel) = _model(hip, oracle, n=20_000, L=100.0, seed=31)
+        m.tick_n(6)                                   # steady state: the tick pair is captured (graph run)
+        rows, _ = m.neighbor_grid_shape()
+        m.clear()
+        m.set_band(12, rows - 12, 0)                  # agents outside rows [11, rows - 12] are now dropped
+        m.append(pos, dest, v0, vel)                  # same count: the old key would match
+        m.tick_n(6)
+        out = m.download()
+        m.close()
+        return out
+    g, e = run(False), run(True)
+    assert len(g[0]) == len(e[0]) < 20_000
+    assert np.array_equal(g[1], e[1]) and all(bit_equal(g[k], e[k]).all() for k in (0, 2, 3))

@@ -1,0 +1,57 @@
+"""pedoni_shard_tick_n -- the driver `bench.py --gpus N` runs -- with world > 1 on one GPU.
+
+A 1-GPU box cannot bring up a real RCCL group of more than one rank (RCCL refuses two ranks on
+one device), so until the driver's 8-GPU run the rank+-1 exchange, the overlapped form on its own
+stream and the re-cut's all-reduce + bulk exchange had never executed with a neighbour.  Here
+every rank is a host thread of ONE child process with its own model and stream, and librccl is
+replaced by tests/loopback_rccl (event-ordered device copies; PEDONI_RCCL_LIB): every line of OUR
+side of the protocol runs -- buffers, offsets, peers, streams, group bracketing, message sizes --
+and the merged bands must equal the unsharded model bit for bit.  What this cannot cover is RCCL
+itself and the wire."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+LOOPBACK = ROOT / "tests" / "loopback_rccl" / "libloopback_rccl.so"
+
+
+def _run(world, mode, extra_env=None):
+    assert LOOPBACK.exists(), "tests/loopback_rccl is not built (python -m pedoni_amd.build)"
+    env = dict(os.environ, PEDONI_RCCL_LIB=str(LOOPBACK), LOOPBACK_RCCL_TIMEOUT_S="30", **(extra_env or {}))
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "loopback_shard_runner.py"), str(world), mode],
+                       env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and lines, f"runner failed ({p.returncode}):\n{p.stdout[-2000:]}\n{p.stderr[-3000:]}"
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("world,mode", [(2, "plain"), (4, "overlap"), (3, "recut"), (5, "recut_overlap")])
+def test_rccl_driven_ticks_equal_the_single_model_bitwise(hip, world, mode):
+    out = _run(world, mode)
+    assert out["ok"], out
+    assert out["count_equal"] and out["dest_equal"] and out["bit_equal"], out
+    # every tick every interior boundary carries one send and one receive each way (+ the token ring)
+    per_tick = 2 * (world - 1)
+    assert out["sends"] == out["recvs"] >= per_tick * (out["ticks"] + 1), out
+    if mode.startswith("recut"):
+        assert out["allreduces"] >= world * (out["ticks"] // 4), out       # one histogram all-reduce per re-cut and rank
+        assert out["bounds1"] != out["bounds0"], "the bands were never re-cut"
+        assert max(out["loads"]) / (sum(out["loads"]) / world) < 1.6, out
+    else:
+        assert out["allreduces"] == 0 and out["bounds1"] == out["bounds0"], out
+
+
+def test_a_failed_send_inside_a_group_leaves_no_group_open(hip):
+    """NCCL_TRY used to return from inside an open ncclGroupStart.  With the
+    first ncclSend made to fail, the entry point reports it, the thread's group depth is back to
+    zero, and the very next exchange works."""
+    out = _run(1, "fault", {"LOOPBACK_RCCL_FAIL_SEND": "0"})
+    assert out["first_error"] and "ncclSend" in out["first_error"], out
+    assert out["depth_after_failure"] == 0, out
+    assert out["second"] is True, out

@@ -322,3 +322,49 @@ def test_bench_picks_the_newest_committed_profile():
     floor = bench.valu_floor(0.09)
     assert floor and floor["profile"] == sorted(Path(bench.ROOT / "profiles").glob("r*_v*_stalls.json"),
                                                 key=bench._by_age)[-1].name
+
+
+# ---- the RCCL side of the shard driver, as far as a CPU can see it ---------------------------
+def test_rccl_group_is_closed_on_every_path(tmp_path):
+    """pedoni_amd/csrc/rccl_group.hpp against a mock (tests/cpp/test_rccl_group.cpp): whatever fails
+    inside ncclGroupStart / ncclGroupEnd, the group is closed, nothing is issued after the first
+    failure and the first failure is the one reported (NCCL_TRY used to return from
+    inside an open group)."""
+    import subprocess
+    exe = tmp_path / "test_rccl_group"
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", f"-I{ROOT / 'pedoni_amd' / 'csrc'}",
+                    "-o", str(exe), str(ROOT / "tests" / "cpp" / "test_rccl_group.cpp")], check=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0 and "all checks passed" in p.stdout, p.stdout + p.stderr
+
+
+def _in_child(code: str, **env):
+    """libpedoni_hip resolves RCCL once per process: each case gets a process of its own."""
+    import os
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                       cwd=str(ROOT), timeout=120)
+    return p.returncode, p.stdout, p.stderr
+
+
+def test_rccl_absent_is_an_error_not_a_crash():
+    """the not-found branch called dlerror() twice (the second call returns NULL:
+    std::string + NULL).  A library name that does not exist must come back as PEDONI_E_HIP."""
+    rc, out, err = _in_child(
+        "from pedoni_amd import abi\n"
+        "try:\n    abi.shard_unique_id(); print('NO ERROR')\n"
+        "except abi.PedoniError as e:\n    print('PedoniError:', e)\n",
+        PEDONI_RCCL_LIB="/nonexistent/librccl_missing.so")
+    assert rc == 0, (rc, out, err)          # (a segfault would be rc = -11)
+    assert "PedoniError" in out and "librccl not found" in out and "librccl_missing" in out, out
+
+
+def test_rccl_override_resolves_the_named_library():
+    """PEDONI_RCCL_LIB selects the transport: the loop-back stand-in of tests/loopback_rccl
+    answers ncclGetUniqueId (no device needed for that call)."""
+    lib = ROOT / "tests" / "loopback_rccl" / "libloopback_rccl.so"
+    assert lib.exists(), "tests/loopback_rccl is not built (python -m pedoni_amd.build)"
+    rc, out, err = _in_child("from pedoni_amd import abi\nprint(abi.shard_unique_id()[:8])\n",
+                             PEDONI_RCCL_LIB=str(lib))
+    assert rc == 0 and "LOOPBACK" in out, (rc, out, err)
