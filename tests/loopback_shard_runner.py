@@ -64,7 +64,7 @@ def main():
               "recut": [(False, 17)], "recut_overlap": [(False, 3), (True, 10), (False, 4)]}[mode]
     ticks = sum(k for _, k in phases)
 
-    models, shards, errors = [None] * world, [None] * world, [None] * world
+    models, shards, errors, loads0 = [None] * world, [None] * world, [None] * world, [0] * world
 
     def rank_main(r):
         try:
@@ -81,6 +81,7 @@ def main():
             if sel.any():
                 m.append(pos[sel], dest[sel], v0[sel], vel[sel])
             s.begin()
+            loads0[r] = s.owned_count()
             for overlap, k in phases:
                 s.set_overlap(overlap)
                 s.tick_n(k)
@@ -129,7 +130,7 @@ def main():
         "bit_equal": bool(len(got[0]) == len(want[0]) and all(bit_equal(got[k], want[k]).all() for k in (0, 2, 3))),
         "sends": int(stats[0]), "recvs": int(stats[1]), "allreduces": int(stats[2]),
         "bounds0": [int(b) for b in bounds], "bounds1": [int(b) for b in new_bounds],
-        "loads": [s.owned_count() for s in shards],
+        "loads0": loads0, "loads": [s.owned_count() for s in shards],
     }
     for s in shards:
         s.close()
