@@ -138,24 +138,113 @@ def cpu_baseline(size, field, obstacles, pos, dest, v0, vel, budget_s: float = 2
     }
 
 
+class Watchdog:
+    """N > 1 runs only.  A hung collective (a rank that died, a mismatched send / receive) would
+    otherwise sit until the driver's own limit and leave no line at all: every stage of the run has
+    a bound, and a rank that outlives it says where it was and exits -- a fresh exit(3), never a
+    re-exec -- which makes torch.distributed.run take the other ranks down too."""
+
+    def __init__(self, rank: int):
+        import threading
+        self.rank, self.name, self.deadline = rank, "start", None
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def stage(self, name: str, bound_s: float) -> None:
+        self.name, self.deadline = name, time.monotonic() + bound_s
+
+    def done(self) -> None:
+        self.deadline = None
+
+    def _run(self) -> None:
+        while True:
+            time.sleep(0.5)
+            d = self.deadline
+            if d is not None and time.monotonic() > d:
+                print(f"[bench] WATCHDOG: rank {self.rank} exceeded its bound in stage '{self.name}'; "
+                      "exiting 3 (no result line)", file=sys.stderr, flush=True)
+                os._exit(3)
+
+
+class SharedField:
+    """What bench needs of host.Field, backed by read-only memory maps of /dev/shm files: rank 0
+    builds the field ONCE (the 1000 x 8000 m field of an 8-GPU run is 1.5 GB and ~8 s of
+    fast marching; 8 ranks building it at once was 12 GB and 8x the threads) and every rank maps
+    it; a rank only ever touches the texel rows of its own band."""
+
+    def __init__(self, unit, distance_map, potential_maps):
+        self.unit, self.distance_map, self.potential_maps = unit, distance_map, potential_maps
+        self.shape = distance_map.shape
+
+
+def shared_field(dist, torch, ctl, rank, size, unit, obstacles, waypoints):
+    """(field, seconds, how): built by rank 0 and mapped by all, or -- if /dev/shm cannot hold it --
+    built by every rank as before.  Collective: every rank calls it."""
+    from pedoni_amd import host
+    tag = f"pedoni_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}"
+    base = Path("/dev/shm") / tag
+    t0 = time.perf_counter()
+    ok = torch.ones(1, dtype=torch.int32, device=ctl)
+    n_maps = torch.zeros(1, dtype=torch.int32, device=ctl)
+    if rank == 0:
+        try:
+            f = host.Field.build(size, unit, obstacles, waypoints)
+            base.mkdir(parents=True, exist_ok=True)
+            np.save(base / "dm.npy", f.distance_map)
+            for k, pm in enumerate(f.potential_maps):
+                np.save(base / f"pm{k}.npy", pm)
+            n_maps[0] = len(f.potential_maps)
+            del f
+        except Exception as e:                          # noqa: BLE001 -- e.g. /dev/shm too small
+            print(f"[bench] rank 0 could not share the field through /dev/shm ({e}); every rank builds its own",
+                  file=sys.stderr)
+            ok[0] = 0
+    dist.broadcast(ok, 0)
+    dist.broadcast(n_maps, 0)
+    if int(ok.item()) == 0:
+        if rank == 0:
+            import shutil
+            shutil.rmtree(base, ignore_errors=True)
+        return host.Field.build(size, unit, obstacles, waypoints), time.perf_counter() - t0, "built by every rank", None
+    dm = np.load(base / "dm.npy", mmap_mode="r")
+    pms = [np.load(base / f"pm{k}.npy", mmap_mode="r") for k in range(int(n_maps.item()))]
+    return SharedField(unit, dm, pms), time.perf_counter() - t0, "built once by rank 0, mapped from /dev/shm", base
+
+
+WORKLOAD_KEYS = ("c2", "c4seg", "c4")
+
+
+def _profile_workload(name: str) -> str:
+    """Which bench workload a committed profile was taken on, from its name (rNN_c4_* ...; C3 otherwise)."""
+    for k in WORKLOAD_KEYS:
+        if f"_{k}_" in name:
+            return k
+    return "c3"
+
+
 def _by_age(path):
     """Sort key of profiles/rNN_vM_* names: numeric fields compare as numbers (v11 after v9)."""
     import re
     return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", path.name)]
 
 
-def pmc_traffic(workload: str):
-    """HBM bytes per force-kernel launch from the newest committed rocprofv3 --pmc passes
-    (profiles/*pmc_force*.json written by tools/pmc_summary.py) for this workload, with the
-    profile it came from -- (bytes, tag) or (None, None)."""
+def pmc_traffic(workload_key: str, kernel_symbol_part: str = "force_kernel"):
+    """Fabric-side bytes per force-kernel launch from the newest committed rocprofv3 --pmc passes
+    (profiles/*pmc_force*.json, tools/pmc_summary.py) taken on THIS workload -- (dict, tag) or
+    (None, None).  `high` = 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction, calibrated
+    on 16 B / lane streams), `low` = FETCH_SIZE + WRITE_SIZE (no correction): this kernel's reads
+    are 4-16 B gathers, for which the correction was measured separately
+    (profiles/r03_gather_traffic.txt).  The counters sit at the TCC's fabric side: Infinity-Cache
+    hits are included, so this is not HBM bytes proper."""
     best = (None, None)
     for p in sorted((ROOT / "profiles").glob("*pmc_force*.json"), key=_by_age):      # rNN_vM names, oldest first
         try:
             d = json.loads(p.read_text())
         except Exception:
             continue
-        if d.get("workload") == workload and d.get("kernel", "").startswith("force"):
-            best = (d.get("hbm_bytes_per_launch"), p.name)
+        if _profile_workload(p.name) == workload_key and kernel_symbol_part in d.get("kernel_symbol", "force_kernel"):
+            fetch, write = (d.get("fetch_size_kb_raw") or 0.0) * 1024.0, (d.get("write_size_kb") or 0.0) * 1024.0
+            best = ({"high": 2.0 * fetch + write, "low": fetch + write}, p.name)
     return best
 
 
@@ -166,34 +255,37 @@ VALU_CYCLES_PER_INST = 2.0
 N_SIMDS = 1024
 
 
-def valu_floor(avg_launch_ms: float):
-    """Instruction-issue floor of the force kernel from the newest committed stall-counter
-    profile (profiles/*_stalls.json, tools/profile_stalls.sh): SQ_INSTS_VALU wave-instructions
-    per launch x 2 cycles / 1024 SIMDs, priced at the clock the profiled launches held
-    (GRBM_GUI_ACTIVE / 8 XCDs per launch / its SQ_BUSY time is not available, so the clock is
-    cycles per launch / the profiled launch duration)."""
+def valu_floor(avg_launch_ms: float, workload_key: str, agents: float, fast: bool):
+    """Instruction-issue floor of the force kernel from the newest committed stall-counter profile
+    of THIS workload and math mode (profiles/*_stalls.json, tools/profile_stalls.sh /
+    profile_workload.sh): VALU wave-instructions PER WAVE of the profiled launches x the waves of
+    this run's launch (64 agents each) x 2 cycles / 1024 SIMDs, at the clock the profiled launches
+    held.  (Round 2 applied a 1e6-agent profile's launch total to any run: 8x off at 8e6 agents.)"""
     best = None
-    names = sorted((ROOT / "profiles").glob("*_stalls.json"),
-                   key=lambda q: (0 if "_base_" in q.name else 1, _by_age(q)))             # rNN_vM names, oldest first
-    for p in names:
+    want = "<1," if fast else "<0,"
+    for p in sorted((ROOT / "profiles").glob("*_stalls.json"), key=_by_age):             # oldest first
+        if _profile_workload(p.name) != workload_key or "_base_" in p.name:
+            continue
         try:
             d = json.loads(p.read_text())
         except Exception:
             continue
         for k, v in d.items():
-            if "force_kernel_queue" in k and "<0," in k and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
-                best = (v, p.name)
+            if "force_kernel" in k and want in k and "trace" not in k and "ablate" not in k \
+                    and v.get("SQ_INSTS_VALU") and v.get("SQ_WAVES"):
+                best = (v, p.name, k)
     if not best:
         return None
-    v, tag = best
-    insts = v["SQ_INSTS_VALU"]
+    v, tag, symbol = best
+    waves = float(int((agents + 63) // 64))
+    per_wave = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
+    insts = per_wave * waves
     floor_cycles = insts * VALU_CYCLES_PER_INST / N_SIMDS
-    launch_cycles = v["GRBM_GUI_ACTIVE"] / 8.0           # rocprofv3 sums the 8 XCDs
     clock_ghz = v.get("clock_ghz") or 2.1
     floor_ms = floor_cycles / (clock_ghz * 1e6)
-    return {"insts_per_launch": insts, "cycles_per_inst": VALU_CYCLES_PER_INST, "simds": N_SIMDS,
-            "floor_ms": floor_ms, "frac": floor_ms / avg_launch_ms,
-            "frac_in_profiled_run": floor_cycles / launch_cycles, "clock_ghz": clock_ghz, "profile": tag}
+    return {"insts_per_launch": insts, "insts_per_wave": per_wave, "waves": waves, "profile_waves": v["SQ_WAVES"],
+            "cycles_per_inst": VALU_CYCLES_PER_INST, "simds": N_SIMDS, "floor_ms": floor_ms,
+            "frac": floor_ms / avg_launch_ms, "clock_ghz": clock_ghz, "profile": tag, "kernel_symbol": symbol}
 
 
 def main() -> None:
@@ -243,11 +335,15 @@ def main() -> None:
     # RCCL / stream plumbing on a single GPU); never set by the driver
     force_sharded = os.environ.get("PEDONI_FORCE_SHARDED") == "1"
     dist = None
+    ranks_seen = 1
+    wd = None
     if world > 1 or force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        wd = Watchdog(rank)
+        wd.stage("torch.distributed init", float(os.environ.get("PEDONI_BENCH_INIT_BOUND_S", "240")))
         import torch.distributed as dist
         # "nccl" IS RCCL on ROCm; PEDONI_DIST_BACKEND=gloo only rehearses the code path
         backend = os.environ.get("PEDONI_DIST_BACKEND", "nccl")
@@ -255,8 +351,21 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        # small control tensors of the collectives: on the device for RCCL, on the host for a gloo rehearsal
+        ctl = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+        seen = torch.ones(1, dtype=torch.int32, device=ctl)
+        dist.all_reduce(seen)                       # the first collective: how many ranks really answer
+        ranks_seen = int(seen.item())
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)   # kernels + collective on one non-default stream
+
+    bound_scale = float(os.environ.get("PEDONI_BENCH_BOUND_SCALE", "1"))   # (tests shrink the bounds)
+
+    def stage(name, bound_s):
+        if wd is not None:
+            wd.stage(name, bound_s * bound_scale)
+            if os.environ.get("PEDONI_BENCH_HANG_AT") == name and rank == world - 1:
+                time.sleep(10_000)                  # test hook: a rank that stops answering (tests/test_cli.py)
 
     G = args.gpus
     n_per = args.agents_per_gpu
@@ -274,14 +383,20 @@ def main() -> None:
         obstacles, waypoints, (width, height), custom_crowd, workload = other_workload(args.workload)
         n_per = 100_000 if args.workload == "c2" else 1_000_000
 
-    t0 = time.perf_counter()
-    field = host.Field.build((width, height), 0.25, obstacles, waypoints)
-    t_field = time.perf_counter() - t0
+    stage("field", 420.0)
+    shm_dir = None
+    if dist is not None and world > 1:
+        field, t_field, field_how, shm_dir = shared_field(dist, torch, ctl, rank, (width, height), 0.25, obstacles, waypoints)
+    else:
+        t0 = time.perf_counter()
+        field = host.Field.build((width, height), 0.25, obstacles, waypoints)
+        t_field, field_how = time.perf_counter() - t0, "built in process"
 
     opt = abi.Options(math_mode=abi.MATH_FAST if args.math == "fast" else abi.MATH_EXACT,
                       gpu_work_size=args.work_size, initial_capacity=int(n_per * 1.3),
                       use_distance_map=args.workload != "c4seg")
     map_rows = bounds = None
+    stage("model", 240.0)
     if G > 1 or force_sharded:
         from pedoni_amd.sharded import ShardedModel, band_rows, default_halo_cap
         rows = int(np.ceil(np.float32(height) / np.float32(opt.neighbor_grid_unit)))   # neighbor_grid.rs:14-20
@@ -289,27 +404,56 @@ def main() -> None:
         # each rank uploads only its band's texel rows of the three maps (1/G of 0.5 GB each at G = 8)
         map_rows = abi.shard_map_rows(bounds[rank], bounds[rank + 1], 0, opt.neighbor_grid_unit, field.unit,
                                       field.shape[0])
-    model = abi.HipModel(opt, (width, height), field.distance_map, field.potential_maps,
+
+    def new_model():
+        m = abi.HipModel(opt, (width, height), field.distance_map, field.potential_maps,
                          field.unit, obstacles, device=local_rank, map_rows=map_rows)
+        if G > 1 or force_sharded:
+            m.set_stream(stream.cuda_stream)
+        return m
+
+    model = new_model()
+    sharded = G > 1 or force_sharded
+    if sharded:
+        lo, hi = bounds[rank], bounds[rank + 1]
+        # this rank's agents: exactly its own band of grid rows (2 m clear of the outer walls)
+        y_lo, y_hi = lo * 1.4 + 0.01, hi * 1.4 - 0.01
+    else:
+        y_lo, y_hi = 0.0, height
+    if custom_crowd is not None:
+        pos, dest, v0, vel = custom_crowd(field)
+    else:
+        pos, dest, v0, vel = uniform_crowd(
+            n_per, (12.0, width - 12.0), (max(y_lo, 2.0), min(y_hi, height - 2.0)), seed=12345 + rank)
 
     exchange = None
-    if G > 1 or force_sharded:
-        model.set_stream(stream.cuda_stream)
+    runner = shard = None
+    verified = None
+    if sharded:
         assert model.neighbor_grid_shape()[0] == rows
         cap = default_halo_cap(int(width * 1.4 * density))
-        runner = shard = None
+
+        def agreed(ok: int) -> bool:
+            # (every rank takes part in every collective below whatever failed locally)
+            flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        def torch_runner(m):
+            r = ShardedModel(m, rank, G, dist, torch, halo_cap=cap, bounds=bounds,
+                             overlap=os.environ.get("PEDONI_OVERLAP") == "1")
+            assert (r.owner_of(pos[:, 1]) == rank).all()
+            r.load(pos, dest, v0, vel)
+            return r
+
+        why = ""
         if os.environ.get("PEDONI_EXCHANGE", "rccl") == "rccl" and dist.get_backend() == "nccl":
             # the driver below the C-ABI: libpedoni_hip owns an RCCL communicator and sends /
             # receives the lists itself (ncclSend / ncclRecv with rank +- 1 on the model's
             # stream).  torch.distributed only carries the 128-byte id and the timing barrier.
-            # (every rank takes part in every collective below whatever failed locally)
-            def agreed(ok: int) -> bool:
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                return int(flag.item()) == 1
-
-            ok, why = 1, ""
-            idt = torch.zeros(abi.SHARD_ID_BYTES, dtype=torch.uint8, device="cuda")
+            stage("rccl communicator + token ring", 240.0)
+            ok = 1
+            idt = torch.zeros(abi.SHARD_ID_BYTES, dtype=torch.uint8, device=ctl)
             if rank == 0:
                 try:
                     idt.copy_(torch.frombuffer(bytearray(abi.shard_unique_id()), dtype=torch.uint8))
@@ -335,7 +479,32 @@ def main() -> None:
             else:
                 ok = 0
             if ok == 1:
-                exchange = "direct RCCL ncclSend/ncclRecv to rank+-1, driven by libpedoni_hip (pedoni_shard_tick_n)"
+                # The direct path had never run with a neighbour before the driver's multi-GPU run
+                # (one GPU per development box).  So it proves itself HERE, every run: 8 ticks of it
+                # (4 plain + 4 overlapped) against 8 ticks of the torch all_gather driver on a second
+                # model with the same crowd; every rank compares the two states bit for bit.
+                stage("verify direct exchange against all_gather", 240.0)
+                try:
+                    model.append(pos, dest, v0, vel)
+                    shard.begin()
+                    shard.tick_n(4); shard.set_overlap(True); shard.tick_n(4); shard.set_overlap(False)
+                    ref_model = new_model()
+                    ref = torch_runner(ref_model)
+                    ref.tick_n(8)
+                    torch.cuda.synchronize()
+                    a, b = model.download(), ref_model.download()
+                    same = all(x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32))
+                               for x, y in zip(a, b))
+                    ref_model.close()
+                    if not same:
+                        ok, why = 0, "direct-exchange state differs from the all_gather driver's after 8 ticks"
+                except Exception as e:             # noqa: BLE001
+                    ok, why = 0, str(e)
+                ok = 1 if agreed(ok) else 0
+                verified = bool(ok)
+            if ok == 1:
+                exchange = ("direct RCCL ncclSend/ncclRecv to rank+-1, driven by libpedoni_hip (pedoni_shard_tick_n); "
+                            "verified in this run: bit-equal to the all_gather driver over 8 ticks (plain + overlapped) on every rank")
             else:
                 print(f"[bench] rank {rank}: direct RCCL path unavailable ({why or 'another rank failed'}); "
                       "falling back to torch.distributed all_gather", file=sys.stderr)
@@ -343,32 +512,27 @@ def main() -> None:
                     shard.close()
                 shard = None
                 model.close()
-                model = abi.HipModel(opt, (width, height), field.distance_map, field.potential_maps,
-                                     field.unit, obstacles, device=local_rank, map_rows=map_rows)
-                model.set_stream(stream.cuda_stream)
+                model = new_model()
         if shard is None:
-            runner = ShardedModel(model, rank, G, dist, torch, halo_cap=cap, bounds=bounds,
-                                  overlap=os.environ.get("PEDONI_OVERLAP") == "1")
+            stage("all_gather driver", 240.0)
+            runner = torch_runner(model)
             exchange = "torch.distributed all_gather_into_tensor (RCCL), driven from Python"
-        lo, hi = bounds[rank], bounds[rank + 1]
-        # this rank's agents: exactly its own band of grid rows (2 m clear of the outer walls)
-        y_lo, y_hi = lo * 1.4 + 0.01, hi * 1.4 - 0.01
-    else:
-        runner = shard = None
-        y_lo, y_hi = 0.0, height
-    if custom_crowd is not None:
-        pos, dest, v0, vel = custom_crowd(field)
-    else:
-        pos, dest, v0, vel = uniform_crowd(
-            n_per, (12.0, width - 12.0), (max(y_lo, 2.0), min(y_hi, height - 2.0)), seed=12345 + rank)
+            if why:
+                exchange += f" (direct path refused: {why[:120]})"
+    if shm_dir is not None:
+        # every rank has uploaded its slices (two models at most): the files can go.  (Mapped pages
+        # stay valid after the unlink; a watchdog exit can no longer leak 1.5 GB of /dev/shm.)
+        dist.barrier()
+        if rank == 0:
+            import shutil
+            shutil.rmtree(shm_dir, ignore_errors=True)
 
     if shard is not None:
-        model.append(pos, dest, v0, vel)
-        shard.begin()
         step_fn = shard.tick_n
         # plain tick (exchange, then the whole update) or overlapped (the next exchange under the
         # interior rows' update)?  Which is faster depends on what the exchange costs on this
         # node: time 20 ticks of each, every rank keeps the mode that was faster for the slowest.
+        stage("tick-form probe", 240.0)
         mode_ms = {}
         for mode in (False, True):
             shard.set_overlap(mode)
@@ -377,17 +541,15 @@ def main() -> None:
             t0 = time.perf_counter()
             shard.tick_n(20)
             torch.cuda.synchronize()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctl)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             mode_ms[mode] = float(t.item()) / 20 * 1e3
         use_overlap = mode_ms[True] < mode_ms[False]
         shard.set_overlap(use_overlap)
         exchange += (f"; tick form: {'overlapped' if use_overlap else 'plain'} "
                      f"(probe: plain {mode_ms[False] * 1e3:.0f} us, overlapped {mode_ms[True] * 1e3:.0f} us per tick; "
-                     "its 50 ticks precede the warmup, so the timed crowd is 50 ticks older than a 1-GPU run's)")
+                     "verification + probe = 58 ticks before the warmup, so the timed crowd is 58 ticks older than a 1-GPU run's)")
     elif runner is not None:
-        assert (runner.owner_of(pos[:, 1]) == rank).all()
-        runner.load(pos, dest, v0, vel)
         step_fn = runner.tick_n
     else:
         model.append(pos, dest, v0, vel)
@@ -398,25 +560,33 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # bounds of the timed stages: generous multiples of what the ticks should take (a tick of 1e6
+    # agents is ~0.12 ms; 50 ms per tick + a minute is two orders of magnitude of slack)
+    tick_bound = lambda k: 60.0 + 0.05 * k * max(1.0, n_per / 1e6)
+    stage("warmup", tick_bound(args.warmup))
     step_fn(args.warmup)
     barrier()
-    sharded = runner is not None or shard is not None
     n_before = model.owned_count() if sharded else model.get_pedestrian_count()
+    # inside the timed region the dominant kernel is event-timed on every `every`-th tick only
+    # (timed ticks launch eagerly inside one hipEvent pair, the others replay the captured tick
+    # pair): every 9th tick on long runs (an odd period: the 8 ticks between two timed ones replay
+    # as 4 pairs), every 3rd on the driver's short ones so that a 20-step run still times 7
+    # launches; the per-kernel pass after the timed region times 20 more, all kernels
+    every = 9 if args.steps >= 90 else 3
     if not args.no_profile:
-        # inside the timed region the dominant kernel is event-timed on every 9th tick only (an odd period: the 8 ticks between two timed ones replay as 4 captured pairs):
-        # timed ticks launch eagerly (+ one hipEvent pair), the others replay the captured tick
-        # pair; the full per-kernel breakdown is a separate pass after the timed region
-        model.profile(True, kernels=[abi.K_FORCE], every=9)
+        model.profile(True, kernels=[abi.K_FORCE], every=every)
         model.kernel_times(reset=True)
+    stage("timed region", tick_bound(args.steps))
     barrier()
     t0 = time.perf_counter()
     step_fn(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    stage("per-kernel pass + reduction", tick_bound(20) + 60.0)
     ktimes = model.kernel_times(reset=True) if not args.no_profile else {}
     model.profile(False)
     n_after = model.owned_count() if sharded else model.get_pedestrian_count()
-    breakdown = {}
+    breakdown, force_pass = {}, None
     if not args.no_profile:
         model.profile(True)
         step_fn(min(args.steps, 20))
@@ -425,13 +595,14 @@ def main() -> None:
         model.profile(False)
         breakdown = {k: v["total_ms"] / max(v["launches"], 1) * (v["launches"] / min(args.steps, 20))
                      for k, v in bt.items() if v["launches"]}
+        force_pass = bt.get("force_integrate")
 
     agents_local = 0.5 * (n_before + n_after)       # despawns during the run are negligible
     if dist is not None and world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        a = torch.tensor([agents_local], dtype=torch.float64, device="cuda")
+        a = torch.tensor([agents_local], dtype=torch.float64, device=ctl)
         dist.all_reduce(a, op=dist.ReduceOp.SUM)
         agents_total = float(a.item())
     else:
@@ -446,28 +617,46 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "agents_total": int(round(agents_total)),
-                       "math_mode": args.math, "parallelism": f"row-bands x{G}; {exchange}" if sharded else "single GPU",
-                       "field_build_s": round(t_field, 2),
+                       "math_mode": args.math,
+                       "parallelism": (f"row-bands x{G} ({ranks_seen} ranks answered the first all-reduce); {exchange}"
+                                       if sharded else "single GPU"),
+                       "field_build_s": round(t_field, 2), "field": field_how,
                        "tick_algorithmic_GBps": BYTES_TICK * value / 1e9},
         }
+        if verified is not None:
+            out["config"]["direct_exchange_verified"] = verified
         fk = ktimes.get("force_integrate")
         if fk and fk["launches"]:
             avg_ms = fk["total_ms"] / fk["launches"]
             achieved = BYTES_FORCE * agents_local / (avg_ms * 1e-3) / 1e9
-            traffic, traffic_tag = pmc_traffic(workload)
-            valu = valu_floor(avg_ms) if args.math == "exact" and args.workload == "c3" and G == 1 else None
+            traffic, traffic_tag = pmc_traffic(args.workload) if G == 1 and n_per in (100_000, 1_000_000) else (None, None)
+            valu = valu_floor(avg_ms, args.workload, agents_local, args.math == "fast") if G == 1 else None
             hbm_frac = achieved / HBM_PEAK_GBS
             out["roofline"] = {
                 # the roof the kernel is closer to: HBM bytes at 8 TB/s, or VALU issue at one
                 # wave instruction per 2 cycles per SIMD (no MFMA on this path)
                 "bound": "valu" if valu and valu["frac"] > hbm_frac else "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": hbm_frac, "traffic": traffic, "traffic_profile": traffic_tag,
+                "frac": hbm_frac,
+                # bytes per launch seen by the TCC's fabric side in the committed --pmc profile of this
+                # workload, with the guide's 2x read correction (`traffic`) and without it
+                # (`traffic_low`): see pmc_traffic()
+                "traffic": traffic["high"] if traffic else None,
+                "traffic_low": traffic["low"] if traffic else None,
+                "traffic_profile": traffic_tag,
+                "traffic_note": ("from the committed rocprofv3 --pmc profile of this workload, not measured in this run; "
+                                 "fabric-side bytes, Infinity-Cache hits included (not HBM bytes proper); the 2x FETCH_SIZE read "
+                                 "correction is calibrated on 16 B/lane streams, this kernel's reads are 4-16 B gathers "
+                                 "(profiles/r03_gather_traffic.txt)") if traffic else None,
                 "kernel": "force_integrate", "avg_launch_ms": avg_ms,
                 "timed_launches": fk["launches"],
                 "algorithmic_bytes_per_launch": BYTES_FORCE * agents_local,
                 "valu": valu,
             }
+            if force_pass and force_pass["launches"]:
+                # the per-kernel pass right after the timed region: 20 more launches of the same kernel
+                out["roofline"]["avg_launch_ms_kernel_pass"] = force_pass["total_ms"] / force_pass["launches"]
+                out["roofline"]["kernel_pass_launches"] = force_pass["launches"]
             out["kernel_ms_per_step"] = breakdown  # separate pass, every kernel event-timed
         else:
             out["roofline"] = None
@@ -484,7 +673,7 @@ def main() -> None:
             fm.tick_n(args.warmup)
             fm.synchronize()
             nb = fm.get_pedestrian_count()
-            fm.profile(True, kernels=[abi.K_FORCE], every=9)
+            fm.profile(True, kernels=[abi.K_FORCE], every=every)
             fm.kernel_times(reset=True)
             t0 = time.perf_counter()
             fm.tick_n(args.steps)
@@ -503,14 +692,21 @@ def main() -> None:
         if G == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((width, height), field, obstacles, pos, dest, v0, vel,
                                                args.cpu_budget, args.workload != "c4seg")
+            # BASELINE.md holds no published number for this metric (the reference publishes none);
+            # the only baseline there is is the CPU port timed in this very run
+            out["vs_baseline"] = value / out["cpu_baseline"]["value"]
+            out["vs_baseline_note"] = "value / cpu_baseline.value of this run (no published reference number exists)"
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
+    stage("teardown", 120.0)
     if shard is not None:
         shard.close()                              # ncclCommDestroy before the model goes
     model.close()
     if dist is not None:
         dist.destroy_process_group()
+    if wd is not None:
+        wd.done()
 
 
 if __name__ == "__main__":
