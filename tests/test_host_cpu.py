@@ -315,13 +315,20 @@ def test_bench_picks_the_newest_committed_profile():
     ordered = sorted((Path(n) for n in names), key=bench._by_age)
     assert [p.name for p in ordered] == ["r01_v6_stalls.json", "r02_v9_stalls.json", "r02_v10_stalls.json",
                                          "r02_v11_stalls.json", "r10_v1_stalls.json"]
-    traffic, tag = bench.pmc_traffic("uniform crowd N=1e6 (1e6/GPU) in a 1000x1000 m box, rho=1/m^2, neighbor grid 1.4 m, "
-                                     "field maps 0.25 m, fp32")
-    newest = sorted(Path(bench.ROOT / "profiles").glob("*pmc_force*.json"), key=bench._by_age)[-1].name
-    assert tag == newest and traffic > 0
-    floor = bench.valu_floor(0.09)
-    assert floor and floor["profile"] == sorted(Path(bench.ROOT / "profiles").glob("r*_v*_stalls.json"),
-                                                key=bench._by_age)[-1].name
+    # profiles are picked per WORKLOAD (rNN_c4_* / _c4seg_ / _c2_ by name, C3 otherwise): the C3 line
+    # must never be priced with a C4 profile (round 2's bench did that)
+    assert [bench._profile_workload(n) for n in ("r03_c4_stalls.json", "r03_c4seg_pmc_force.json", "r03_c2_stalls.json",
+                                                 "r02_v12_stalls.json")] == ["c4", "c4seg", "c2", "c3"]
+    for key in ("c3", "c4", "c4seg", "c2"):
+        traffic, tag = bench.pmc_traffic(key)
+        mine = [q for q in sorted(Path(bench.ROOT / "profiles").glob("*pmc_force*.json"), key=bench._by_age)
+                if bench._profile_workload(q.name) == key]
+        assert tag == mine[-1].name and traffic["high"] > traffic["low"] > 0
+        floor = bench.valu_floor(0.09, key, 1_000_000 if key != "c2" else 100_000, fast=False)
+        assert floor and bench._profile_workload(floor["profile"]) == key and "<0," in floor["kernel_symbol"]
+    # an 8e6-agent launch is priced with 8x the waves of the 1e6-agent profile, not with its launch total
+    f1, f8 = bench.valu_floor(0.09, "c3", 1_000_000, False), bench.valu_floor(0.72, "c3", 8_000_000, False)
+    assert abs(f8["insts_per_launch"] / f1["insts_per_launch"] - 8.0) < 1e-3 and abs(f8["frac"] / f1["frac"] - 1.0) < 1e-3
 
 
 # ---- the RCCL side of the shard driver, as far as a CPU can see it ---------------------------
