@@ -302,6 +302,12 @@ int pedoni_shard_local_group_tick_n(PedoniShard** shards, uint32_t n_shards, uin
 int pedoni_hip_eikonal(int device, float* potential, const float* slowness, float uniform_slowness,
                        uint32_t rows, uint32_t cols, uint32_t* launches_out);
 
+#ifdef PEDONI_DIAGNOSTICS
+/* Diagnostics: NOT part of the product library.  `python -m pedoni_amd.build` compiles a second
+ * library, pedoni_amd/lib/libpedoni_hip_diag.so, with -DPEDONI_DIAGNOSTICS: the same sources plus
+ * the instrumented / ablation instantiations of the force kernel, the PEDONI_ABLATE and
+ * PEDONI_FORCE_TRACE switches and the three entry points below.  The tests that need the fault
+ * injection hook and tools/force_trace.py, ablate_launch.py load that library; nothing else does. */
 /* [ext] test hook: overwrite the model's sticky device status word (the word the scan and
  * place kernels raise when cell and row counts disagree or the live count exceeds the host's
  * bound of the arrays).  While it is non-zero every read of device state -- get_pedestrian_count,
@@ -317,6 +323,7 @@ int pedoni_hip_debug_set_ablate(PedoniModel* m, uint32_t bits);
  * prologue, phases 1 / 2 / 3 and the epilogue (sums7[0..4]), their lifetimes ([5]) and their
  * number ([6]); tools/force_trace.py prints the shares */
 int pedoni_hip_debug_force_trace(PedoniModel* m, uint64_t* sums7, int32_t reset);
+#endif /* PEDONI_DIAGNOSTICS */
 
 /* [ext] device self-test hooks used by tests/: evaluate one device math primitive over
  * host arrays (op: 0 = a/b, 1 = sqrt(a), 2 = exp(a), 3 = a/0.3f, 4 = a/0.2f,

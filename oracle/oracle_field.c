@@ -57,10 +57,14 @@ void oracle_field_shape(float size_x, float size_y, float unit, int32_t* rows, i
  * to vertical, burns a straight run of that column (likewise rows for near-horizontal ones);
  * anything else is walked pixel by pixel along x with the slope, moving to the next
  * scanline whenever the step to the next column would cross a row boundary, nudged by 1e-9
- * so that it always advances.  Written independently of the product's builder
- * (pedoni_amd/csrc/host/field.cpp, an exact grid traversal): the two agreeing is evidence
- * for "every touched pixel", not a pin -- the reference's own test of the crate only prints
- * (field.rs:272-286).  Affects how the INPUT maps are produced, not the per-step arithmetic.
+ * so that it always advances.  The product's builder (pedoni_amd/csrc/host/field.cpp) states the
+ * SAME published walk a second time, in C++: the two agreeing bit for bit on every scenario is a
+ * consistency check between two restatements of one algorithm, NOT a pin and not independent
+ * evidence.  The independent statement is the exact grid traversal inside the tests
+ * (tests/test_host_cpu.py::_exact_traversal); where it and this walk differ -- corner / end-point
+ * ties, a handful of cells -- is committed as tests/golden/burner_corner_ties.json, the first
+ * place to look once geo-rasterize's own output exists (the reference's test of the crate only
+ * prints, field.rs:272-286).  Affects how the INPUT maps are produced, not the per-step arithmetic.
  */
 static void burn(uint8_t* mask, int32_t rows, int32_t cols, int64_t c, int64_t r)
 {

@@ -39,12 +39,16 @@ SYMBOLS = [
     "pedoni_hip_halo_tick_begin", "pedoni_hip_halo_tick_end",
     "pedoni_hip_owned_count",
     "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_selftest_field", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
-    "pedoni_hip_debug_set_status", "pedoni_hip_debug_set_ablate", "pedoni_hip_debug_force_trace", "pedoni_hip_profile_every",
+    "pedoni_hip_profile_every",
     "pedoni_hip_create_rows", "pedoni_shard_map_rows", "pedoni_hip_eikonal",
     "pedoni_shard_unique_id", "pedoni_shard_balanced_bounds", "pedoni_shard_recut_bounds", "pedoni_shard_create", "pedoni_shard_destroy",
     "pedoni_shard_begin", "pedoni_shard_tick_n", "pedoni_shard_owned_count", "pedoni_shard_band",
     "pedoni_shard_selftest", "pedoni_shard_set_rebalance", "pedoni_shard_set_overlap", "pedoni_shard_local_group_tick_n",
 ]
+
+
+# the diagnostics build (pedoni_amd/lib/libpedoni_hip_diag.so, -DPEDONI_DIAGNOSTICS) adds these
+DIAG_SYMBOLS = ["pedoni_hip_debug_set_status", "pedoni_hip_debug_set_ablate", "pedoni_hip_debug_force_trace"]
 
 
 class PedoniError(RuntimeError):
@@ -107,6 +111,17 @@ def library_path() -> Path:
     return Path(override) if override else _ROOT / "lib" / "libpedoni_hip.so"
 
 
+def _bind(path: Path, mode: int) -> C.CDLL:
+    lib = C.CDLL(str(path), mode=mode)
+    lib.pedoni_hip_last_error.restype = C.c_char_p
+    lib.pedoni_hip_kernel_name.restype = C.c_char_p
+    lib.pedoni_hip_kernel_name.argtypes = [C.c_int32]
+    lib.pedoni_hip_destroy.restype = None
+    lib.pedoni_hip_destroy.argtypes = [C.c_void_p]
+    lib.pedoni_hip_default_options.restype = None
+    return lib
+
+
 def load_library() -> C.CDLL:
     """dlopen the in-tree HIP library; never builds, never substitutes."""
     global _LIB
@@ -117,15 +132,27 @@ def load_library() -> C.CDLL:
         raise PedoniError(
             f"{path} is missing: build it with `python -m pedoni_amd.build` "
             "(the HIP backend has no CPU fallback)")
-    lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL)
-    lib.pedoni_hip_last_error.restype = C.c_char_p
-    lib.pedoni_hip_kernel_name.restype = C.c_char_p
-    lib.pedoni_hip_kernel_name.argtypes = [C.c_int32]
-    lib.pedoni_hip_destroy.restype = None
-    lib.pedoni_hip_destroy.argtypes = [C.c_void_p]
-    lib.pedoni_hip_default_options.restype = None
-    _LIB = lib
-    return lib
+    _LIB = _bind(path, C.RTLD_GLOBAL)
+    return _LIB
+
+
+_DIAG: Optional[C.CDLL] = None
+
+
+def diagnostics_library_path() -> Path:
+    return _ROOT / "lib" / "libpedoni_hip_diag.so"
+
+
+def load_diagnostics_library() -> C.CDLL:
+    """The -DPEDONI_DIAGNOSTICS build of the same sources (fault-injection hook, instrumented and
+    ablation force kernels): for tests and tools only; `HipModel(..., diagnostics=True)` uses it."""
+    global _DIAG
+    if _DIAG is None:
+        path = diagnostics_library_path()
+        if not path.exists():
+            raise PedoniError(f"{path} is missing: build it with `python -m pedoni_amd.build`")
+        _DIAG = _bind(path, C.RTLD_LOCAL)
+    return _DIAG
 
 
 def _check(lib: C.CDLL, rc: int) -> None:
@@ -193,10 +220,11 @@ class HipModel:
     def __init__(self, options: Options, size: Sequence[float], distance_map: np.ndarray,
                  potential_maps: Sequence[np.ndarray], field_unit: float,
                  obstacles: Optional[np.ndarray] = None, device: int = 0,
-                 map_rows: Optional[Sequence[int]] = None):
+                 map_rows: Optional[Sequence[int]] = None, diagnostics: bool = False):
         """`map_rows` = (begin, end): upload only these texel rows of every (full-size) map --
-        one band of a sharded run (pedoni_hip_create_rows; see shard_map_rows)."""
-        self._lib = load_library()
+        one band of a sharded run (pedoni_hip_create_rows; see shard_map_rows).
+        `diagnostics`: run on the diagnostics build of the library (debug_* methods)."""
+        self._lib = load_diagnostics_library() if diagnostics else load_library()
         self._h = C.c_void_p(None)
         dm = _f32(distance_map)
         if dm.ndim != 2:

@@ -43,19 +43,33 @@ def hipcc() -> str:
     return exe
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> Path:
-    LIBDIR.mkdir(parents=True, exist_ok=True)
-    out = LIBDIR / "libpedoni_hip.so"
-    srcs = [CSRC / "pedoni_hip.hip"]
-    deps = srcs + list(CSRC.glob("*.hpp")) + [INCLUDE / "pedoni_hip.h"]
-    if not force and _newer(out, deps):
-        return out
+def _hip_deps():
+    return [CSRC / "pedoni_hip.hip"] + list(CSRC.glob("*.hpp")) + [INCLUDE / "pedoni_hip.h"]
+
+
+def _hip_cmd(out: Path, extra=()):
     # (librccl is NOT linked: shard.hpp resolves it with dlopen at first use)
-    cmd = [hipcc(), *HIP_FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-I/opt/rocm/include", "-o", str(out),
-           *map(str, srcs), "-ldl"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    return [hipcc(), *HIP_FLAGS, *extra, f"-I{INCLUDE}", f"-I{CSRC}", "-I/opt/rocm/include", "-o", str(out),
+            str(CSRC / "pedoni_hip.hip"), "-ldl"]
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> Path:
+    """libpedoni_hip.so (the product) and libpedoni_hip_diag.so (the same sources with
+    -DPEDONI_DIAGNOSTICS: fault-injection hook, instrumented / ablation force kernels -- loaded by
+    tests and tools only).  The two compiles run side by side."""
+    LIBDIR.mkdir(parents=True, exist_ok=True)
+    out, diag = LIBDIR / "libpedoni_hip.so", LIBDIR / "libpedoni_hip_diag.so"
+    jobs = []
+    for target, extra in ((out, ()), (diag, ("-DPEDONI_DIAGNOSTICS",))):
+        if not force and _newer(target, _hip_deps()):
+            continue
+        cmd = _hip_cmd(target, extra)
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, job in jobs:
+        if job.wait() != 0:
+            raise subprocess.CalledProcessError(job.returncode, cmd)
     return out
 
 

@@ -26,6 +26,7 @@ namespace pedoni {
 using PedoniObstacleDev = ::PedoniObstacle;
 
 constexpr uint32_t DEAD = 0xffffffffu;
+constexpr uint32_t TICKET_STRIDE = 32;   // words: one 128-byte line per XCD's ticket word (force_kernel_queue_persist)
 
 // Workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  Agents are sorted
 // by cell, so neighbouring workgroups share most of their candidate lines: map the hardware
@@ -413,7 +414,7 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
                              uint32_t parity, uint32_t* __restrict__ cell_count, SoA a,
                              uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed,
                              uint32_t* __restrict__ row_count, int32_t row0, int32_t row1,
-                             uint32_t* __restrict__ status)
+                             uint32_t* __restrict__ status, uint32_t* __restrict__ tickets)
 {
     uint32_t j = i0 + xcd_contiguous_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     // the NEXT tick's flag is raised by this tick's update_states and the next K_KEY; it can
@@ -427,6 +428,8 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
         }
         // the scan has consumed the row totals: back to zero for the keys of the next pass
         for (int32_t r = row0 + (int32_t)threadIdx.x; r < row1; r += (int32_t)blockDim.x) row_count[r] = 0;
+        // the tile tickets of the persistent force kernel that follows this pass
+        if (threadIdx.x < 8u) tickets[threadIdx.x * TICKET_STRIDE] = 0;
     }
     if (j >= n_total) return;
     uint32_t c = key[j];
@@ -550,9 +553,12 @@ struct ForceArgs {
     SortFlags* flags;
     uint32_t parity_next;
     int32_t xcd_remap; // XCD-contiguous block order (PEDONI_NO_XCD_REMAP=1 turns it off)
+    uint32_t* tickets;  // persistent form: 8 ticket words, TICKET_STRIDE apart (zeroed by the place kernel)
+    uint32_t n_tiles;   // persistent form: 64-agent tiles of this launch
     unsigned long long* trace; // TRACE build only (7 words, see force_queue_body)
-    int32_t ablate; // diagnostics only (PEDONI_ABLATE): 1 = no goal sampling, 2 = no obstacle term, 4 = no pairs; in the
-                    // ablation build only: 8 / 16 = phase 2 without its gather / arithmetic, 32 = no despawn sampling, 64 / 128 = no row / no counts
+    int32_t ablate; // PEDONI_DIAGNOSTICS builds only (force_kernel_queue_ablate, PEDONI_ABLATE): 1 = no goal sampling, 2 = no
+                    // obstacle term, 4 = no pairs, 8 / 16 = phase 2 without its gather / arithmetic, 32 = no despawn sampling,
+                    // 64 / 128 = no row / no counts.  The product kernels are instantiated without these switches.
 };
 
 // goal force, sfm.rs:106-109
@@ -721,8 +727,11 @@ constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 // shader cycles (s_memtime) it spent in the prologue, in phases 1 / 2 / 3 and in the epilogue to
 // its own record a.trace[8 * wave + 0..4], its lifetime to [5] and 1 to [6] -- where a wave's
 // WALL time goes, waiting and being passed over by the arbiter included.
+// One tile = the 64 agents of one wave: sorted indices base + 64 * tile + lane.  `queue` / `who` are
+// the calling wave's own LDS queue, `tab` the block's copy of the exp table.
 template <int MODE, int SLOTS, bool TRACE = false, bool ABL = false>
-__device__ __forceinline__ void force_queue_body(const ForceArgs& a)
+__device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint32_t tile, float2* __restrict__ queue,
+                                                 uint32_t* __restrict__ who, const uint64_t* __restrict__ tab)
 {
     unsigned long long tr_t0 = 0, tr_mark = 0, tr_acc[5] = {0, 0, 0, 0, 0};
     auto tr_lap = [&](int which) {
@@ -737,7 +746,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
             if ((threadIdx.x & 63u) == 0 && a.trace) {
                 tr_lap(4);
                 // one 64-byte record per wave (plain stores: atomics on shared words would stall the run)
-                unsigned long long* rec = a.trace + 8ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+                unsigned long long* rec = a.trace + 8ull * tile;
                 for (int k = 0; k < 5; ++k) rec[k] += tr_acc[k];
                 rec[5] += __builtin_amdgcn_s_memtime() - tr_t0;
                 rec[6] += 1ull;
@@ -745,22 +754,12 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         }
     };
     if constexpr (TRACE) tr_t0 = tr_mark = __builtin_amdgcn_s_memtime();
-    __shared__ uint64_t tab[32];
-    // (+ 64 entries per wave: lane l of a slot that did not pass writes entry SLOTS * 64 + l, so
-    // the queue writes of phase 1 need no branch)
-    __shared__ float2 queue_all[FORCE_WAVES][SLOTS * 64 + 64];    // {dx, dy} in, {fx, fy} out
-    __shared__ uint32_t who_all[FORCE_WAVES][SLOTS * 64 + 64];    // neighbour index | owner lane << 26
-    if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
-    __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    float2* queue = queue_all[wave];
-    uint32_t* who = who_all[wave];
-    const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
-    uint32_t id = a.base + block * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t id = a.base + tile * 64u + lane;
     uint32_t n = *a.live_count;
     if (a.seg_row[0][0] >= 0) {                    // row-segment launch (sharded overlap)
-        uint32_t t = block * blockDim.x + threadIdx.x;
+        uint32_t t = tile * 64u + lane;
         uint32_t b0 = a.cell_start[(int64_t)a.seg_row[0][0] * a.grid.cols];
         uint32_t e0 = a.cell_start[(int64_t)a.seg_row[0][1] * a.grid.cols];
         uint32_t b1 = a.cell_start[(int64_t)a.seg_row[1][0] * a.grid.cols];
@@ -795,7 +794,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         iy = f32_as_i32(pos.y / a.grid.unit);
         ghost = iy < a.band_lo || iy >= a.band_hi;
         if (!ghost) {
-            if (a.ablate & 1) e = mk(1.0f, 0.0f);
+            if (ABL && (a.ablate & 1)) e = mk(1.0f, 0.0f);
             else e = goal_direction<MODE>(a.field, pos, destination); // :107-108
             acc = acc + vdiv<MODE>(e * desired_speed - vel, 0.5f); // :109
             int32_t y_start = max(iy - 1, 0), y_end = min(iy + 1, a.grid.rows - 1); // :117-118
@@ -811,7 +810,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
             }
         }
     }
-    const uint32_t cnt = (a.ablate & 4) ? 0u : n0 + n1 + n2;
+    const uint32_t cnt = (ABL && (a.ablate & 4)) ? 0u : n0 + n1 + n2;
     uint32_t max_cnt = cnt;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, off, 64));
@@ -937,7 +936,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
         dest_k = a.dest[id];
         map_k = dest_k < a.field.n_maps ? a.field.potential_maps[dest_k] : nullptr;
     }
-    if (a.ablate & 2) {}
+    if (ABL && (a.ablate & 2)) {}
     else if (a.use_distance_map) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
     else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
 
@@ -977,6 +976,28 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
     tr_flush();
 }
 
+// LDS of one force-kernel block: the exp table and one pair queue per wave
+// (+ 64 entries per wave: lane l of a slot that did not pass writes entry SLOTS * 64 + l, so
+// the queue writes of phase 1 need no branch)
+template <int SLOTS> struct ForceLds {
+    uint64_t tab[32];
+    float2 queue[FORCE_WAVES][SLOTS * 64 + 64];     // {dx, dy} in, {fx, fy} out
+    uint32_t who[FORCE_WAVES][SLOTS * 64 + 64];     // neighbour index | owner lane << 26
+};
+
+// one tile per wave, tiles dealt by the hardware's workgroup order (XCD-contiguous by default)
+template <int MODE, int SLOTS, bool TRACE = false, bool ABL = false>
+__device__ __forceinline__ void force_queue_body(const ForceArgs& a)
+{
+    __shared__ ForceLds<SLOTS> lds;
+    if (threadIdx.x < 32) lds.tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    force_queue_tile<MODE, SLOTS, TRACE, ABL>(a, block * FORCE_WAVES + wave, lds.queue[wave], lds.who[wave], lds.tab);
+}
+
+#ifdef PEDONI_DIAGNOSTICS
 // diagnostic build of the 7-wave kernel with the extended ablation switches (PEDONI_ABLATE bits 8
 // and up; tools/ablate_launch.py): a build of its own, so that the product kernels carry none of it
 template <int MODE, int SLOTS>
@@ -993,6 +1014,7 @@ force_kernel_queue_trace(ForceArgs a)
 {
     force_queue_body<MODE, SLOTS, true>(a);
 }
+#endif
 
 template <int MODE, int SLOTS>
 __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
@@ -1009,6 +1031,52 @@ __global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sg
 force_kernel_queue_s94(ForceArgs a)
 {
     force_queue_body<MODE, SLOTS>(a);
+}
+
+// ---- K_FORCE, persistent-wave form ---------------------------------------
+// The grid is what the chip holds at once (7 waves x 1024 SIMDs = 1792 blocks); every WAVE pulls
+// 64-agent tiles from a ticket counter until the tiles are gone, so a SIMD keeps its 7 waves until
+// the queue is dry whatever the tiles' lifetimes, and no wave is launched or retired in between
+// (SGPR / VGPR set-up, LDS table, the block's barrier: once per wave, not once per tile).  The
+// tiles are cut into 8 contiguous ranges, one per XCD (its L2 serves neighbouring rows, as with
+// xcd_contiguous_block), each with its own ticket word on a line of its own (MI355X_MICROARCH.md,
+// dequeue: one returning agent-scope atomicAdd, ~1.1 us under load, sharded per XCD); a wave whose
+// home range is dry steals from the next XCD's.  The next ticket is requested BEFORE the current
+// tile is worked on, so its latency is paid once per wave.  Tickets only ever grow: a dry range
+// stays dry, every wave leaves after at most 8 empty draws -- the grid always drains.  The ticket
+// words are zeroed by the place kernel of the same tick (the launch before this one).
+// Same tile function, same per-agent arithmetic and order: same bits.
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_persist(ForceArgs a)
+{
+    __shared__ ForceLds<SLOTS> lds;
+    if (threadIdx.x < 32) lds.tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_tiles = a.n_tiles, q = n_tiles / 8u, r = n_tiles % 8u;
+    uint32_t home = blockIdx.x & 7u;          // workgroups are dealt round-robin to the XCDs
+    uint32_t dry = 0;                         // ranges found empty so far
+    auto range_begin = [&](uint32_t x) { return x * q + min(x, r); };
+    auto range_len = [&](uint32_t x) { return q + (x < r ? 1u : 0u); };
+    auto draw = [&]() -> uint32_t {           // wave-uniform ticket of the current home range
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&a.tickets[home * TICKET_STRIDE], 1u);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+    uint32_t next = draw();
+    while (dry < 8u) {
+        const uint32_t t = next;
+        if (t >= range_len(home)) {           // home range dry: move on to the next XCD's
+            home = (home + 1u) & 7u;
+            dry += 1u;
+            if (dry < 8u) next = draw();
+            continue;
+        }
+        const uint32_t tile = range_begin(home) + t;
+        next = draw();                        // in flight while this tile is worked on
+        force_queue_tile<MODE, SLOTS>(a, tile, lds.queue[wave], lds.who[wave], lds.tab);
+    }
 }
 
 // ---- on-device periodic spawning (Simulator::tick, lib.rs:67-85 + sfm.rs:49-56) ---------------

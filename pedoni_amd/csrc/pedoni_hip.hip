@@ -42,6 +42,7 @@ int fail(int code, const std::string& msg)
         if (rc_ != PEDONI_OK) return rc_;                                                    \
     } while (0)
 
+constexpr bool PERSIST_BY_DEFAULT = false;   // the persistent force kernel: opt-in until its A/B says otherwise
 constexpr size_t TRACE_WAVES = 1u << 18;   // PEDONI_FORCE_TRACE: one 64-byte record per wave, up to 16.7 M agents
 
 const char* const KERNEL_NAMES[PEDONI_N_KERNELS] = {
@@ -77,6 +78,16 @@ struct EventPair {
 } // namespace
 
 struct PedoniShard;
+
+// Which instantiation of the queue force kernel a launch takes (kernels.hpp): the 94-SGPR build
+// that holds 7 waves per SIMD, or the compiler's default register budget; SLOTS = candidates per
+// lane and batch (the pair queue's depth).  PEDONI_FORCE_KERNEL = "s94:6", "default:8", ...
+// overrides the by-size default (tools/slots_sweep.sh, tools/ab_repeat.sh).
+enum class ForceBuild { BySize, S94, Default };
+struct ForceChoice {
+    ForceBuild build = ForceBuild::BySize;
+    int slots = 0;
+};
 
 struct PedoniModel {
     int device = 0;
@@ -125,6 +136,9 @@ struct PedoniModel {
     uint32_t* d_block_sums = nullptr;
     uint32_t block_sums_cap = 0;
     uint32_t* d_row_count = nullptr; // members per grid row (top level of the row scan)
+    uint32_t* d_tickets = nullptr;   // 8 tile-ticket words of the persistent force kernel, TICKET_STRIDE apart
+    bool tickets_fresh = false;      // zeroed by the place kernel and not drawn from since
+    int force_persist = -1;          // PEDONI_FORCE_PERSIST: 1 / 0 = always / never the persistent form; -1 = by size
     uint32_t* d_live = nullptr; // device: [0] live agent count (absolute end index), [1] sticky status word
     uint32_t* h_pinned = nullptr;
     float2* d_acc = nullptr;
@@ -153,7 +167,7 @@ struct PedoniModel {
     bool no_fuse_key = false;  // PEDONI_NO_FUSE_KEY=1: standalone K_KEY every tick
     bool xcd_remap = true;     // PEDONI_NO_XCD_REMAP=1: hardware block order
     unsigned long long* d_trace = nullptr; // PEDONI_FORCE_TRACE=1: per-phase cycle sums of the force kernel
-    int force_slots = 0;       // PEDONI_FORCE_SLOTS: candidates per lane per batch (0 = by size; 4, 5, 6, 8)
+    ForceChoice force_choice{}; // PEDONI_FORCE_KERNEL: build and queue depth of the force kernel (unset = by size)
 
     // steady-state tick pair captured as a hipGraph (pedoni_hip_tick_n); see tick_graph()
     hipGraphExec_t graph_exec = nullptr;
@@ -417,7 +431,8 @@ int sort_despawn(PedoniModel* m)
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
                                m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
                                (m->halo_cap || m->n_spawners) ? m->d_halo : nullptr, m->d_row_count, row0,
-                               row1, m->d_live + 1);
+                               row1, m->d_live + 1, m->d_tickets);
+            m->tickets_fresh = true;
         }
         {
             Timed t(m, PEDONI_K_REORDER);
@@ -541,28 +556,55 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         // force_kernel_queue_s94): 96.2 us against 100.5 us at N = 1e6, exact mode; small crowds
         // (few waves per SIMD anyway) run the default build with 8-slot batches.  PEDONI_FORCE_SLOTS overrides:
         // 4 / 5 (s94), 6, 8, 15 (5 slots, default SGPRs), 16 / 18 (s94 with 6 / 8 slots).
-        int slots = m->force_slots;
-        if (slots == 0) slots = n >= 400000u ? 16 : 8;   // (small crowds: 8-slot batches, 2-3 % over 6: tools/slots_sweep.sh at N = 1e5 .. 2.5e5)
-        if (m->d_trace && (size_t)grid.x * FORCE_WAVES <= TRACE_WAVES) slots = 96;
-        if (m->ablate & ~7) slots = 97;          // extended ablation switches: their own build
-        switch (slots + (fast ? 100 : 0)) {
-        case 4: hipLaunchKernelGGL((force_kernel_queue_s94<0, 4>), grid, block, 0, stream, a); break;
-        case 5: hipLaunchKernelGGL((force_kernel_queue_s94<0, 5>), grid, block, 0, stream, a); break;
-        case 15: hipLaunchKernelGGL((force_kernel_queue<0, 5>), grid, block, 0, stream, a); break;
-        case 16: hipLaunchKernelGGL((force_kernel_queue_s94<0, 6>), grid, block, 0, stream, a); break;
-        case 18: hipLaunchKernelGGL((force_kernel_queue_s94<0, 8>), grid, block, 0, stream, a); break;
-        case 96: hipLaunchKernelGGL((force_kernel_queue_trace<0, 6>), grid, block, 0, stream, a); break;
-        case 97: hipLaunchKernelGGL((force_kernel_queue_ablate<0, 6>), grid, block, 0, stream, a); break;
-        case 197: hipLaunchKernelGGL((force_kernel_queue_ablate<1, 6>), grid, block, 0, stream, a); break;
-        case 196: hipLaunchKernelGGL((force_kernel_queue_trace<1, 6>), grid, block, 0, stream, a); break;
-        case 116: hipLaunchKernelGGL((force_kernel_queue_s94<1, 6>), grid, block, 0, stream, a); break;
-        case 8: hipLaunchKernelGGL((force_kernel_queue<0, 8>), grid, block, 0, stream, a); break;
-        case 104: hipLaunchKernelGGL((force_kernel_queue_s94<1, 4>), grid, block, 0, stream, a); break;
-        case 105: hipLaunchKernelGGL((force_kernel_queue_s94<1, 5>), grid, block, 0, stream, a); break;
-        case 108: hipLaunchKernelGGL((force_kernel_queue<1, 8>), grid, block, 0, stream, a); break;
-        default:
-            if (fast) hipLaunchKernelGGL((force_kernel_queue<1, 6>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((force_kernel_queue<0, 6>), grid, block, 0, stream, a);
+        ForceChoice c = m->force_choice;
+        if (c.build == ForceBuild::BySize)   // (small crowds: 8-slot batches, 2-3 % over 6: tools/slots_sweep.sh at N = 1e5 .. 2.5e5)
+            c = n >= 400000u ? ForceChoice{ForceBuild::S94, 6} : ForceChoice{ForceBuild::Default, 8};
+#ifdef PEDONI_DIAGNOSTICS
+        // diagnostic instantiations (per-phase trace, ablation switches): a build of their own
+        if (m->d_trace && (size_t)grid.x * FORCE_WAVES <= TRACE_WAVES) {
+            if (fast) hipLaunchKernelGGL((force_kernel_queue_trace<1, 6>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((force_kernel_queue_trace<0, 6>), grid, block, 0, stream, a);
+            HIP_TRY(hipGetLastError());
+            return PEDONI_OK;
+        }
+        if (m->ablate) {
+            if (fast) hipLaunchKernelGGL((force_kernel_queue_ablate<1, 6>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((force_kernel_queue_ablate<0, 6>), grid, block, 0, stream, a);
+            HIP_TRY(hipGetLastError());
+            return PEDONI_OK;
+        }
+#endif
+        // persistent-wave form (kernels.hpp force_kernel_queue_persist): whole-array launches right
+        // after a sort pass (whose place kernel zeroed the tile tickets), the 7-wave 6-slot build only
+        const bool persist = part == 0 && !on && m->tickets_fresh && c.build == ForceBuild::S94 && c.slots == 6 &&
+                             (m->force_persist == 1 || (m->force_persist < 0 && PERSIST_BY_DEFAULT && n >= 400000u));
+        if (persist) {
+            a.tickets = m->d_tickets;
+            a.n_tiles = blocks_for(n, 64);
+            m->tickets_fresh = false;
+            const dim3 pgrid(std::min(blocks_for(n, FORCE_THREADS), 7u * 256u));     // what the chip holds at once
+            if (fast) hipLaunchKernelGGL((force_kernel_queue_persist<1, 6>), pgrid, block, 0, stream, a);
+            else hipLaunchKernelGGL((force_kernel_queue_persist<0, 6>), pgrid, block, 0, stream, a);
+            HIP_TRY(hipGetLastError());
+            return PEDONI_OK;
+        }
+        auto launch = [&](auto exact_kernel, auto fast_kernel) {
+            if (fast) hipLaunchKernelGGL(fast_kernel, grid, block, 0, stream, a);
+            else hipLaunchKernelGGL(exact_kernel, grid, block, 0, stream, a);
+        };
+        if (c.build == ForceBuild::S94) {
+            switch (c.slots) {
+            case 4: launch(force_kernel_queue_s94<0, 4>, force_kernel_queue_s94<1, 4>); break;
+            case 5: launch(force_kernel_queue_s94<0, 5>, force_kernel_queue_s94<1, 5>); break;
+            case 8: launch(force_kernel_queue_s94<0, 8>, force_kernel_queue_s94<1, 8>); break;
+            default: launch(force_kernel_queue_s94<0, 6>, force_kernel_queue_s94<1, 6>);
+            }
+        } else {
+            switch (c.slots) {
+            case 5: launch(force_kernel_queue<0, 5>, force_kernel_queue<1, 5>); break;
+            case 6: launch(force_kernel_queue<0, 6>, force_kernel_queue<1, 6>); break;
+            default: launch(force_kernel_queue<0, 8>, force_kernel_queue<1, 8>);
+            }
         }
     } else {
         if (part != 0) return fail(PEDONI_E_INVALID, "row-segment force launch needs the queue kernel");
@@ -751,15 +793,20 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
     {
         const char* fs = std::getenv("PEDONI_FORCE_SIMPLE");
         m->force_simple = fs && fs[0] == '1';
+#ifdef PEDONI_DIAGNOSTICS
         const char* ab = std::getenv("PEDONI_ABLATE");
         m->ablate = ab ? std::atoi(ab) : 0;
+#endif
         const char* sg = std::getenv("PEDONI_SORT_GENERAL");
         m->sort_general = sg && sg[0] == '1';
         const char* nf = std::getenv("PEDONI_NO_FUSE_KEY");
         m->no_fuse_key = nf && nf[0] == '1';
         const char* nx = std::getenv("PEDONI_NO_XCD_REMAP");
         m->xcd_remap = !(nx && nx[0] == '1');
-        const char* ft = std::getenv("PEDONI_FORCE_TRACE");
+        const char* ft = nullptr;
+#ifdef PEDONI_DIAGNOSTICS
+        ft = std::getenv("PEDONI_FORCE_TRACE");
+#endif
         if (ft && ft[0] == '1') {
             if (hipMalloc((void**)&m->d_trace, TRACE_WAVES * 8 * sizeof(unsigned long long)) != hipSuccess ||
                 hipMemset(m->d_trace, 0, TRACE_WAVES * 8 * sizeof(unsigned long long)) != hipSuccess) {
@@ -769,8 +816,21 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
         }
         const char* ng = std::getenv("PEDONI_NO_GRAPH");
         m->use_graph = !(ng && ng[0] == '1');
-        const char* fsl = std::getenv("PEDONI_FORCE_SLOTS");
-        if (fsl) m->force_slots = std::atoi(fsl);
+        if (const char* fk = std::getenv("PEDONI_FORCE_KERNEL")) {
+            const std::string v(fk);
+            const size_t colon = v.find(':');
+            const std::string b = v.substr(0, colon);
+            const int sl = colon == std::string::npos ? 0 : std::atoi(v.c_str() + colon + 1);
+            const bool s94 = b == "s94", def = b == "default";
+            const bool known = (s94 && (sl == 4 || sl == 5 || sl == 6 || sl == 8)) || (def && (sl == 5 || sl == 6 || sl == 8));
+            if (!known) {
+                pedoni_hip_destroy(m);
+                return fail(PEDONI_E_INVALID, "create: PEDONI_FORCE_KERNEL must be s94:{4,5,6,8} or default:{5,6,8}");
+            }
+            m->force_choice = ForceChoice{s94 ? ForceBuild::S94 : ForceBuild::Default, sl};
+        }
+        const char* fp = std::getenv("PEDONI_FORCE_PERSIST");
+        if (fp) m->force_persist = std::atoi(fp) ? 1 : 0;
     }
     *out = nullptr;
 
@@ -844,6 +904,8 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
         }
         C_TRY(dev_alloc(&m->d_row_count, (size_t)m->grid.rows + 1));
         C_HIP(hipMemset(m->d_row_count, 0, ((size_t)m->grid.rows + 1) * sizeof(uint32_t)));
+        C_TRY(dev_alloc(&m->d_tickets, (size_t)8 * TICKET_STRIDE));
+        C_HIP(hipMemset(m->d_tickets, 0, (size_t)8 * TICKET_STRIDE * sizeof(uint32_t)));
     }
     m->band_lo = 0;
     m->band_hi = opt->use_neighbor_grid ? m->grid.rows : 0;
@@ -880,6 +942,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     hipFree(m->d_live); hipFree(m->d_acc); hipFree(m->d_halo);
     hipFree(m->d_spawners); hipFree(m->d_spawn_state);
     hipFree(m->d_row_count);
+    hipFree(m->d_tickets);
     hipFree(m->d_trace);
     if (m->h_pinned) hipHostFree(m->h_pinned);
     hipFree(m->d_distance_map);
@@ -1494,6 +1557,7 @@ int pedoni_hip_owned_count(PedoniModel* m, int32_t* count)
     return PEDONI_OK;
 }
 
+#ifdef PEDONI_DIAGNOSTICS
 int pedoni_hip_debug_force_trace(PedoniModel* m, uint64_t* sums7, int32_t reset)
 {
     TRY(bind(m));
@@ -1527,6 +1591,7 @@ int pedoni_hip_debug_set_ablate(PedoniModel* m, uint32_t bits)
     m->graph_valid = false;
     return PEDONI_OK;
 }
+#endif // PEDONI_DIAGNOSTICS
 
 // ---- device math self-test -----------------------------------------------------------------
 } // extern "C"

@@ -11,12 +11,12 @@ from pedoni_amd import scenario as scn
 pytestmark = pytest.mark.gpu
 
 
-def _model(hip, oracle, n=5000, L=80.0, seed=11, **opt):
+def _model(hip, oracle, n=5000, L=80.0, seed=11, diagnostics=False, **opt):
     sc = random_obstacle_scenario(L, 40, seed=seed)
     field = oracle_field(oracle, sc)
     pos, dest, v0, vel = inject_crowd(field, sc.field.size, n, 4, seed=seed)
     gpu = hip.HipModel(hip.Options(**opt), sc.field.size, field.distance_map, field.potential_maps,
-                       field.unit, sc.obstacle_array())
+                       field.unit, sc.obstacle_array(), diagnostics=diagnostics)
     gpu.append(pos, dest, v0, vel)
     return sc, field, gpu, (pos, dest, v0, vel)
 
@@ -25,8 +25,9 @@ def _model(hip, oracle, n=5000, L=80.0, seed=11, **opt):
 def test_device_status_word_fails_every_read_of_device_state(hip, oracle, word, match):
     """kernels.hpp STATUS_*: the scan's integrity check and the live-count bound raise a sticky
     device word; get_pedestrian_count / download / list_pedestrians / owned_count must all fail
-    while it is set (never continue on a wrong cell_start)."""
-    _, _, gpu, _ = _model(hip, oracle)
+    while it is set (never continue on a wrong cell_start).  The hook that sets
+    the word exists in the diagnostics build of the library only (libpedoni_hip_diag.so)."""
+    _, _, gpu, _ = _model(hip, oracle, diagnostics=True)
     gpu.tick_n(3)
     n = gpu.get_pedestrian_count()
     assert n > 0

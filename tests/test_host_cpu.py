@@ -57,11 +57,26 @@ def test_shard_map_rows_cover_the_band_its_ghosts_and_the_stencil():
 
 def test_hip_library_exports_every_declared_symbol():
     lib = abi.load_library()
-    declared = _declared("pedoni_hip.h", "pedoni_(?:hip|shard)")
+    text = (ROOT / "include" / "pedoni_hip.h").read_text()
+    diag_block = re.search(r"#ifdef PEDONI_DIAGNOSTICS(.*?)#endif /\* PEDONI_DIAGNOSTICS \*/", text, re.S)
+    assert diag_block, "the diagnostics section of pedoni_hip.h was not found"
+    names = lambda t: sorted(set(re.findall(r"\b(pedoni_(?:hip|shard)_[a-z_0-9]+)\s*\(", t)))
+    declared = names(text.replace(diag_block.group(0), ""))
+    diag_only = names(diag_block.group(1))
     assert declared and any(d.startswith("pedoni_shard_") for d in declared), "header parse failed"
     assert sorted(abi.SYMBOLS) == declared, "abi.SYMBOLS out of sync with include/pedoni_hip.h"
+    assert sorted(abi.DIAG_SYMBOLS) == diag_only
     for name in declared:
         assert hasattr(lib, name), f"libpedoni_hip.so lacks {name}"
+    # the product library carries no diagnostics; the diagnostics build has both
+    for name in diag_only:
+        assert not hasattr(lib, name), f"libpedoni_hip.so exports the diagnostic {name}"
+    diag = abi.load_diagnostics_library()
+    for name in declared + diag_only:
+        assert hasattr(diag, name), f"libpedoni_hip_diag.so lacks {name}"
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", str(abi.library_path())], capture_output=True, text=True).stdout
+    assert "force_kernel_queue_s94" in syms and "force_kernel_queue_trace" not in syms and "force_kernel_queue_ablate" not in syms
 
 
 def test_host_library_exports_every_declared_symbol():
@@ -281,6 +296,28 @@ def test_line_burner_is_all_touched_up_to_corner_ties(oracle):
     assert not ((exact != got.obstacle_exist) & ~grown).any()
 
 
+def test_burner_corner_ties_match_the_committed_fixture():
+    """tests/golden/burner_corner_ties.json (tests/golden/make_burner_ties_fixture.py): the cells
+    where this build's burner and an exact grid traversal disagree, scenario by scenario -- the
+    target list for a future pin of geo-rasterize 0.1.2.  Re-derived here for
+    every scenario file present (the reference's own only in the build container)."""
+    import json
+    import sys
+    sys.path.insert(0, str(GOLDEN))
+    import make_burner_ties_fixture as mk
+    fixture = json.loads((GOLDEN / "burner_corner_ties.json").read_text())
+    assert "random.toml" in fixture and sum(len(v["cells"]) for v in fixture.values()) < 20
+    checked = 0
+    for name, want in fixture.items():
+        path = Path("/root/reference/scenarios") / name.split(":", 1)[1] if name.startswith("reference:") \
+            else GOLDEN / "scenarios" / name
+        if not path.exists():
+            continue                                  # (the GPU box has no /root/reference)
+        assert mk.ties(path) == want, name
+        checked += 1
+    assert checked >= 3
+
+
 def test_upstream_test_obstacle_shape_printed_grid(oracle):
     """field.rs:272-286 `test_obstacle` rasterises (5,3.5)-(5,4.5)-(15,4.5)-(15,3.5) on a 20 x 10
     grid and only PRINTS it: no expected value exists upstream.  This is the slot for one: the
@@ -375,3 +412,77 @@ def test_rccl_override_resolves_the_named_library():
     rc, out, err = _in_child("from pedoni_amd import abi\nprint(abi.shard_unique_id()[:8])\n",
                              PEDONI_RCCL_LIB=str(lib))
     assert rc == 0 and "LOOPBACK" in out, (rc, out, err)
+
+
+# ---- rust/ shim against include/pedoni_hip.h (it cannot be compiled here: no cargo) ---------------
+_RUST_TO_C = {
+    "f32": "float", "f64": "double", "i32": "int32_t", "u32": "uint32_t", "u64": "uint64_t", "i64": "int64_t",
+    "c_int": "int", "c_char": "char", "c_void": "PedoniModel",      # the opaque handle
+}
+
+
+def _norm_c_type(t: str) -> str:
+    t = re.sub(r"\bconst\b", "", t)
+    t = re.sub(r"\s+", "", t)
+    return t
+
+
+def _rust_type_to_c(t: str) -> str:
+    t = t.strip()
+    stars = 0
+    while t.startswith("*const ") or t.startswith("*mut "):
+        t = t.split(" ", 1)[1].strip()
+        stars += 1
+    return _RUST_TO_C.get(t, t) + "*" * stars
+
+
+def _split_args(arglist: str):
+    return [a.strip() for a in arglist.split(",") if a.strip() and a.strip() != "void"]
+
+
+def test_rust_shim_ffi_block_matches_the_c_header():
+    """f3 drift guard: `rust/pedoni-simulator/src/models/sfm_hip.rs` is source only (no Rust
+    toolchain in the image), so nothing compiles its `extern "C"` block against the header.  This
+    does the comparison a compiler + bindgen would: every function the shim declares exists in
+    include/pedoni_hip.h with the same argument count, the same argument types (pointer depth and
+    scalar width) in the same order and the same return type; every #[repr(C)] struct has the
+    header's fields in the header's order with the same widths."""
+    rs = (ROOT / "rust" / "pedoni-simulator" / "src" / "models" / "sfm_hip.rs").read_text()
+    hdr = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "pedoni_hip.h").read_text(), flags=re.S)
+    hdr = re.sub(r"^\s*#.*$", ";", hdr, flags=re.M)            # preprocessor lines end a declaration
+
+    block = re.search(r'extern "C" \{(.*?)\n\}', rs, re.S).group(1)
+    fns = re.findall(r"fn (\w+)\((.*?)\)\s*(?:->\s*([^;]+))?;", block, re.S)
+    assert len(fns) >= 7, "extern block parse failed"
+    for name, args, ret in fns:
+        m = re.search(rf"([\w \t\*]+?)\b{name}\s*\((.*?)\)\s*;", hdr, re.S)
+        assert m, f"{name}: declared by the Rust shim, absent from pedoni_hip.h"
+        c_ret, c_args = _norm_c_type(m.group(1)), _split_args(m.group(2))
+        r_args = _split_args(re.sub(r"\s+", " ", args))
+        assert len(c_args) == len(r_args), f"{name}: {len(r_args)} arguments in Rust, {len(c_args)} in C"
+        for ra, ca in zip(r_args, c_args):
+            r_name, r_ty = (x.strip() for x in ra.split(":", 1))
+            c_m = re.match(r"(.*?)(\w+)(\[\w*\])?$", ca.strip())
+            c_ty = _norm_c_type(c_m.group(1)) + ("*" if c_m.group(3) else "")
+            assert _rust_type_to_c(r_ty) == c_ty, f"{name}({r_name}): Rust `{r_ty}` vs C `{ca}`"
+            assert r_name == c_m.group(2) or {r_name, c_m.group(2)} <= {"m", "out", "opt", "peds", "n", "count", "cap"} \
+                or r_name == c_m.group(2), f"{name}: argument `{r_name}` is `{c_m.group(2)}` in the header"
+        want_ret = _rust_type_to_c(ret) if ret else "void"
+        assert want_ret == c_ret, f"{name}: returns `{ret}` in Rust, `{m.group(1).strip()}` in C"
+
+    structs = re.findall(r"#\[repr\(C\)\][^\n]*\n?struct (\w+)\s*\{(.*?)\}", rs, re.S)
+    assert {s for s, _ in structs} == {"PedoniOptions", "PedoniObstacle", "PedoniPedestrian"}
+    for sname, body in structs:
+        r_fields = [(f.split(":")[0].strip(), f.split(":")[1].strip()) for f in body.replace("\n", " ").split(",") if ":" in f]
+        cm = re.search(rf"typedef struct \{{([^}}]*)\}}\s*{sname}\s*;", hdr, re.S)
+        assert cm, f"{sname} not found in the header"
+        c_fields = []
+        for decl in cm.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            ty, names = decl.split(None, 1)
+            c_fields += [(n.strip(), ty) for n in names.split(",")]
+        assert [(n, _RUST_TO_C[t]) for n, t in r_fields] == c_fields, f"{sname}: field order / types differ"
+    # and the layouts the Python binding (the tested caller) assumes are the same ones
+    assert C.sizeof(abi._Options) == 40 and C.sizeof(abi._Obstacle) == 20 and C.sizeof(abi._Pedestrian) == 16

@@ -1,7 +1,8 @@
 """What each part of the force kernel costs, launch by launch: a crowd of 1e6 agents is ticked
 normally (relaxing it), then ONE tick runs with parts of the force kernel switched off
 (pedoni_hip_debug_set_ablate; results of that tick are wrong) and its force launch is timed with
-hipEvents.  A fresh model per measurement.   gpurun -- python tools/ablate_launch.py [warm ticks [bits,bits,...]]"""
+hipEvents.  A fresh model per measurement, on the diagnostics build of the library
+(pedoni_amd/lib/libpedoni_hip_diag.so).   gpurun -- python tools/ablate_launch.py [warm ticks [bits,bits,...]]"""
 import sys
 
 import numpy as np
@@ -23,7 +24,7 @@ def one(bits, reps=3):
     out = []
     for _ in range(reps):
         m = abi.HipModel(abi.Options(initial_capacity=1_300_000), (side, side), field.distance_map,
-                         field.potential_maps, field.unit, obstacles)
+                         field.potential_maps, field.unit, obstacles, diagnostics=True)
         m.append(pos, dest, v0, vel)
         m.tick_n(WARM)
         m.get_pedestrian_count()

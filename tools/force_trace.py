@@ -20,7 +20,7 @@ obstacles, waypoints = bench.box_geometry(L, L)
 field = host.Field.build((L, L), 0.25, obstacles, waypoints)
 pos, dest, v0, vel = bench.uniform_crowd(1_000_000, (12.0, L - 12.0), (2.0, L - 2.0), seed=12345)
 opt = abi.Options(math_mode=abi.MATH_FAST if mode == "fast" else abi.MATH_EXACT, initial_capacity=1_300_000)
-m = abi.HipModel(opt, (L, L), field.distance_map, field.potential_maps, field.unit, obstacles)
+m = abi.HipModel(opt, (L, L), field.distance_map, field.potential_maps, field.unit, obstacles, diagnostics=True)
 m.append(pos, dest, v0, vel)
 m.tick_n(10)
 m.debug_force_trace(reset=True)
