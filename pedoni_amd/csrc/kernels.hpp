@@ -428,8 +428,8 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
         }
         // the scan has consumed the row totals: back to zero for the keys of the next pass
         for (int32_t r = row0 + (int32_t)threadIdx.x; r < row1; r += (int32_t)blockDim.x) row_count[r] = 0;
-        // the tile tickets of the persistent force kernel that follows this pass
-        if (threadIdx.x < 8u) tickets[threadIdx.x * TICKET_STRIDE] = 0;
+        // (diagnostics build: the tile tickets of the persistent force kernel that follows this pass)
+        if (tickets && threadIdx.x < 8u) tickets[threadIdx.x * TICKET_STRIDE] = 0;
     }
     if (j >= n_total) return;
     uint32_t c = key[j];
@@ -730,7 +730,7 @@ constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 // One tile = the 64 agents of one wave: sorted indices base + 64 * tile + lane.  `queue` / `who` are
 // the calling wave's own LDS queue, `tab` the block's copy of the exp table.
 template <int MODE, int SLOTS, bool TRACE = false, bool ABL = false>
-__device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint32_t tile, float2* __restrict__ queue,
+__device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint32_t t0, float2* __restrict__ queue,
                                                  uint32_t* __restrict__ who, const uint64_t* __restrict__ tab)
 {
     unsigned long long tr_t0 = 0, tr_mark = 0, tr_acc[5] = {0, 0, 0, 0, 0};
@@ -746,7 +746,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
             if ((threadIdx.x & 63u) == 0 && a.trace) {
                 tr_lap(4);
                 // one 64-byte record per wave (plain stores: atomics on shared words would stall the run)
-                unsigned long long* rec = a.trace + 8ull * tile;
+                unsigned long long* rec = a.trace + 8ull * (t0 >> 6);
                 for (int k = 0; k < 5; ++k) rec[k] += tr_acc[k];
                 rec[5] += __builtin_amdgcn_s_memtime() - tr_t0;
                 rec[6] += 1ull;
@@ -756,10 +756,10 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
     if constexpr (TRACE) tr_t0 = tr_mark = __builtin_amdgcn_s_memtime();
 
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t id = a.base + tile * 64u + lane;
+    uint32_t id = a.base + t0;
     uint32_t n = *a.live_count;
     if (a.seg_row[0][0] >= 0) {                    // row-segment launch (sharded overlap)
-        uint32_t t = tile * 64u + lane;
+        uint32_t t = t0;
         uint32_t b0 = a.cell_start[(int64_t)a.seg_row[0][0] * a.grid.cols];
         uint32_t e0 = a.cell_start[(int64_t)a.seg_row[0][1] * a.grid.cols];
         uint32_t b1 = a.cell_start[(int64_t)a.seg_row[1][0] * a.grid.cols];
@@ -979,22 +979,21 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
 // LDS of one force-kernel block: the exp table and one pair queue per wave
 // (+ 64 entries per wave: lane l of a slot that did not pass writes entry SLOTS * 64 + l, so
 // the queue writes of phase 1 need no branch)
-template <int SLOTS> struct ForceLds {
-    uint64_t tab[32];
-    float2 queue[FORCE_WAVES][SLOTS * 64 + 64];     // {dx, dy} in, {fx, fy} out
-    uint32_t who[FORCE_WAVES][SLOTS * 64 + 64];     // neighbour index | owner lane << 26
-};
+#define PEDONI_FORCE_LDS(SLOTS)                                                                        \
+    __shared__ uint64_t tab[32];                                                                       \
+    __shared__ float2 queue_all[FORCE_WAVES][SLOTS * 64 + 64]; /* {dx, dy} in, {fx, fy} out */         \
+    __shared__ uint32_t who_all[FORCE_WAVES][SLOTS * 64 + 64]; /* neighbour index | owner lane << 26 */ \
+    if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];                                   \
+    __syncthreads()
 
 // one tile per wave, tiles dealt by the hardware's workgroup order (XCD-contiguous by default)
 template <int MODE, int SLOTS, bool TRACE = false, bool ABL = false>
 __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
 {
-    __shared__ ForceLds<SLOTS> lds;
-    if (threadIdx.x < 32) lds.tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
-    __syncthreads();
+    PEDONI_FORCE_LDS(SLOTS);
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
-    force_queue_tile<MODE, SLOTS, TRACE, ABL>(a, block * FORCE_WAVES + wave, lds.queue[wave], lds.who[wave], lds.tab);
+    force_queue_tile<MODE, SLOTS, TRACE, ABL>(a, block * blockDim.x + threadIdx.x, queue_all[wave], who_all[wave], tab);
 }
 
 #ifdef PEDONI_DIAGNOSTICS
@@ -1033,51 +1032,116 @@ force_kernel_queue_s94(ForceArgs a)
     force_queue_body<MODE, SLOTS>(a);
 }
 
-// ---- K_FORCE, persistent-wave form ---------------------------------------
-// The grid is what the chip holds at once (7 waves x 1024 SIMDs = 1792 blocks); every WAVE pulls
-// 64-agent tiles from a ticket counter until the tiles are gone, so a SIMD keeps its 7 waves until
-// the queue is dry whatever the tiles' lifetimes, and no wave is launched or retired in between
-// (SGPR / VGPR set-up, LDS table, the block's barrier: once per wave, not once per tile).  The
-// tiles are cut into 8 contiguous ranges, one per XCD (its L2 serves neighbouring rows, as with
-// xcd_contiguous_block), each with its own ticket word on a line of its own (MI355X_MICROARCH.md,
-// dequeue: one returning agent-scope atomicAdd, ~1.1 us under load, sharded per XCD); a wave whose
-// home range is dry steals from the next XCD's.  The next ticket is requested BEFORE the current
-// tile is worked on, so its latency is paid once per wave.  Tickets only ever grow: a dry range
-// stays dry, every wave leaves after at most 8 empty draws -- the grid always drains.  The ticket
-// words are zeroed by the place kernel of the same tick (the launch before this one).
-// Same tile function, same per-agent arithmetic and order: same bits.
+#ifdef PEDONI_DIAGNOSTICS
+// ---- K_FORCE, persistent-wave forms: a MEASURED DEAD END, kept in the diagnostics build only -----
+// VERDICT r2 item 2 asked for the persistent form to be measured instead of argued away: a grid of
+// what the chip holds at once (w waves x 1024 SIMDs), every wave working through 64-agent tiles of
+// its XCD's contiguous range -- first tile static, the next ones from a per-XCD ticket word -- so
+// that a SIMD keeps its waves until the tiles are gone.  Same tile function, same bits (the parity
+// suites pass with PEDONI_FORCE_PERSIST set).  Result on MI355X, N = 1e6, exact mode, force kernel
+// (profiles/r03_persist_ab.txt; one-tile-per-wave kernel: 88.7 us at 7 waves, 92.5 at 6):
+//   * tickets by agent-scope atomicAdd, drawn between tiles: 172-226 us.  A returning atomic is
+//     ordered with the wave's loads (vmcnt), and an agent-scope one executes at the memory side,
+//     behind the ~1e6 count atomics the kernel itself issues: ~25 us per draw.
+//   * the next ticket requested before the tile and read after it: 112-137 us (every load of the
+//     tile issued after the draw still returns behind it).
+//   * the draw at workgroup scope (executes in the XCD's own L2; only waves of that XCD draw from
+//     that word; no stealing): 105-112 us.
+//   * no tickets at all, static tile strides: 95.1 us at 6 waves (92.5 without the loop), 97.2 at
+//     5, 104.9 at 7.  At the 7-wave budget (72 VGPRs, 94 SGPRs) the tile function has not one
+//     register to spare: whatever is carried around it -- even with the loop state parked in LDS
+//     and the arguments re-read from the kernarg segment per tile -- costs 64-80 bytes of scratch
+//     per lane inside the tile's loops.
+// The hardware's dispatcher already refills a CU as workgroups retire; keeping the waves brings
+// nothing this kernel can use, and costs registers it does not have.  Not a product path.
+template <int MODE, int SLOTS>
+__device__ __forceinline__ void force_persist_body()
+{
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the symbol: address space 4 is a device notion)
+    PEDONI_FORCE_LDS(SLOTS);
+    // The arguments are re-read from the kernarg segment for every tile (scalar loads, scalar
+    // cache): held across the loop they are ~50 SGPRs live through every tile on top of the tile's
+    // own, which the compiler spills to VGPR lanes inside the tile's loops.
+    typedef const ForceArgs __attribute__((address_space(4))) KArgs;
+    KArgs* pa = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // range x: tiles [x * q + min(x, r), + q + (x < r)); its first n_static(x) tiles are the static
+    // first tiles of the waves whose home it is (blocks x, x + 8, ...: dealt round-robin to the XCDs)
+    auto n_static = [&](uint32_t x) { return ((gridDim.x + 7u - x) >> 3) * (uint32_t)FORCE_WAVES; };
+    uint32_t home = blockIdx.x & 7u;
+    uint32_t t = (blockIdx.x >> 3) * (uint32_t)FORCE_WAVES + wave;     // static first tile
+    for (;;) {
+        asm volatile("" : "+s"(pa));          // (opaque: the arguments are re-read per tile, not carried around the loop)
+        const uint32_t n_tiles = pa->n_tiles, q = n_tiles / 8u, r = n_tiles % 8u;
+        if (t < q + (home < r ? 1u : 0u)) {
+            // the NEXT ticket is requested before this tile is worked on and read after it: a returning
+            // atomic waits (vmcnt, in order) for every store and count atomic issued before it, i.e. a
+            // draw BETWEEN two tiles waited for the whole tail of the tile before it -- ~28 us per
+            // draw, measured: the loop ran at half the speed of the same loop with static tiles
+            uint32_t drawn = 0;
+            if (lane == 0)
+                drawn = __hip_atomic_fetch_add(&pa->tickets[home * TICKET_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const ForceArgs a = *pa;
+            force_queue_tile<MODE, SLOTS>(a, (home * q + min(home, r) + t) * 64u + lane, queue_all[wave], who_all[wave], tab);
+            t = __builtin_amdgcn_readfirstlane(drawn) + n_static(home);
+        } else {
+            break;
+        }
+    }
+#endif
+}
+
+// bisecting experiment: the same loop with STATIC tiles (tile, tile + waves of the range, ...): no
+// tickets, no atomics, no stealing
+template <int MODE, int SLOTS>
+__device__ __forceinline__ void force_static_body()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    PEDONI_FORCE_LDS(SLOTS);
+    typedef const ForceArgs __attribute__((address_space(4))) KArgs;
+    KArgs* pa = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t home = blockIdx.x & 7u;
+    const uint32_t step = ((gridDim.x + 7u - home) >> 3) * (uint32_t)FORCE_WAVES;
+    for (uint32_t t = (blockIdx.x >> 3) * (uint32_t)FORCE_WAVES + wave;; t += step) {
+        asm volatile("" : "+s"(pa));
+        const uint32_t n_tiles = pa->n_tiles, q = n_tiles / 8u, r = n_tiles % 8u;
+        if (t >= q + (home < r ? 1u : 0u)) break;
+        const ForceArgs a = *pa;
+        force_queue_tile<MODE, SLOTS>(a, (home * q + min(home, r) + t) * 64u + lane, queue_all[wave], who_all[wave], tab);
+    }
+#endif
+}
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_static5(ForceArgs) { force_static_body<MODE, SLOTS>(); }
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 6) force_kernel_queue_static6(ForceArgs) { force_static_body<MODE, SLOTS>(); }
 template <int MODE, int SLOTS>
 __global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
-force_kernel_queue_persist(ForceArgs a)
+force_kernel_queue_static7(ForceArgs) { force_static_body<MODE, SLOTS>(); }
+
+// at the one-tile-per-wave kernel's budget (7 waves per SIMD: 72 VGPRs, 94 SGPRs) ...
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_persist(ForceArgs)
 {
-    __shared__ ForceLds<SLOTS> lds;
-    if (threadIdx.x < 32) lds.tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
-    __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t n_tiles = a.n_tiles, q = n_tiles / 8u, r = n_tiles % 8u;
-    uint32_t home = blockIdx.x & 7u;          // workgroups are dealt round-robin to the XCDs
-    uint32_t dry = 0;                         // ranges found empty so far
-    auto range_begin = [&](uint32_t x) { return x * q + min(x, r); };
-    auto range_len = [&](uint32_t x) { return q + (x < r ? 1u : 0u); };
-    auto draw = [&]() -> uint32_t {           // wave-uniform ticket of the current home range
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(&a.tickets[home * TICKET_STRIDE], 1u);
-        return __builtin_amdgcn_readfirstlane(t);
-    };
-    uint32_t next = draw();
-    while (dry < 8u) {
-        const uint32_t t = next;
-        if (t >= range_len(home)) {           // home range dry: move on to the next XCD's
-            home = (home + 1u) & 7u;
-            dry += 1u;
-            if (dry < 8u) next = draw();
-            continue;
-        }
-        const uint32_t tile = range_begin(home) + t;
-        next = draw();                        // in flight while this tile is worked on
-        force_queue_tile<MODE, SLOTS>(a, tile, lds.queue[wave], lds.who[wave], lds.tab);
-    }
+    force_persist_body<MODE, SLOTS>();
 }
+
+// ... at 6 waves per SIMD (<= 80 VGPRs, default SGPRs) ...
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 6) force_kernel_queue_persist6(ForceArgs)
+{
+    force_persist_body<MODE, SLOTS>();
+}
+
+// ... and with no cap at all (93 VGPRs: 5 waves per SIMD, nothing spilled)
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_persist5(ForceArgs)
+{
+    force_persist_body<MODE, SLOTS>();
+}
+#endif // PEDONI_DIAGNOSTICS
 
 // ---- on-device periodic spawning (Simulator::tick, lib.rs:67-85 + sfm.rs:49-56) ---------------
 // One thread replays, draw for draw, what the host does each tick: per periodic spawner

@@ -42,7 +42,6 @@ int fail(int code, const std::string& msg)
         if (rc_ != PEDONI_OK) return rc_;                                                    \
     } while (0)
 
-constexpr bool PERSIST_BY_DEFAULT = false;   // the persistent force kernel: opt-in until its A/B says otherwise
 constexpr size_t TRACE_WAVES = 1u << 18;   // PEDONI_FORCE_TRACE: one 64-byte record per wave, up to 16.7 M agents
 
 const char* const KERNEL_NAMES[PEDONI_N_KERNELS] = {
@@ -138,7 +137,7 @@ struct PedoniModel {
     uint32_t* d_row_count = nullptr; // members per grid row (top level of the row scan)
     uint32_t* d_tickets = nullptr;   // 8 tile-ticket words of the persistent force kernel, TICKET_STRIDE apart
     bool tickets_fresh = false;      // zeroed by the place kernel and not drawn from since
-    int force_persist = -1;          // PEDONI_FORCE_PERSIST: 1 / 0 = always / never the persistent form; -1 = by size
+    int force_persist = -1;          // PEDONI_FORCE_PERSIST: 0 never, 1 / 7, 6, 5 = the persistent form at that residency; -1 = by size
     uint32_t* d_live = nullptr; // device: [0] live agent count (absolute end index), [1] sticky status word
     uint32_t* h_pinned = nullptr;
     float2* d_acc = nullptr;
@@ -431,7 +430,7 @@ int sort_despawn(PedoniModel* m)
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
                                m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
                                (m->halo_cap || m->n_spawners) ? m->d_halo : nullptr, m->d_row_count, row0,
-                               row1, m->d_live + 1, m->d_tickets);
+                               row1, m->d_live + 1, m->force_persist > 0 ? m->d_tickets : nullptr);
             m->tickets_fresh = true;
         }
         {
@@ -574,20 +573,44 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
             return PEDONI_OK;
         }
 #endif
-        // persistent-wave form (kernels.hpp force_kernel_queue_persist): whole-array launches right
-        // after a sort pass (whose place kernel zeroed the tile tickets), the 7-wave 6-slot build only
+#ifdef PEDONI_DIAGNOSTICS
+        // persistent-wave forms (kernels.hpp: a measured dead end, PEDONI_FORCE_PERSIST): whole-array
+        // launches right after a sort pass, whose place kernel zeroed the tile tickets
         const bool persist = part == 0 && !on && m->tickets_fresh && c.build == ForceBuild::S94 && c.slots == 6 &&
-                             (m->force_persist == 1 || (m->force_persist < 0 && PERSIST_BY_DEFAULT && n >= 400000u));
+                             m->force_persist > 0;
         if (persist) {
             a.tickets = m->d_tickets;
             a.n_tiles = blocks_for(n, 64);
             m->tickets_fresh = false;
-            const dim3 pgrid(std::min(blocks_for(n, FORCE_THREADS), 7u * 256u));     // what the chip holds at once
-            if (fast) hipLaunchKernelGGL((force_kernel_queue_persist<1, 6>), pgrid, block, 0, stream, a);
-            else hipLaunchKernelGGL((force_kernel_queue_persist<0, 6>), pgrid, block, 0, stream, a);
+            // the grid is what the chip holds at once: waves per SIMD (= blocks per CU) x 256 CUs
+            const uint32_t waves = m->force_persist == 5 || m->force_persist == 6 ? (uint32_t)m->force_persist : 7u;
+            const dim3 pgrid(std::min(blocks_for(n, FORCE_THREADS), waves * 256u));
+            if (m->force_persist >= 15 && m->force_persist <= 17) {
+                const dim3 sgrid(std::min(blocks_for(n, FORCE_THREADS), (uint32_t)(m->force_persist - 10) * 256u));
+                if (m->force_persist == 15) {
+                    if (fast) hipLaunchKernelGGL((force_kernel_queue_static5<1, 6>), sgrid, block, 0, stream, a);
+                    else hipLaunchKernelGGL((force_kernel_queue_static5<0, 6>), sgrid, block, 0, stream, a);
+                } else if (m->force_persist == 16) {
+                    if (fast) hipLaunchKernelGGL((force_kernel_queue_static6<1, 6>), sgrid, block, 0, stream, a);
+                    else hipLaunchKernelGGL((force_kernel_queue_static6<0, 6>), sgrid, block, 0, stream, a);
+                } else {
+                    if (fast) hipLaunchKernelGGL((force_kernel_queue_static7<1, 6>), sgrid, block, 0, stream, a);
+                    else hipLaunchKernelGGL((force_kernel_queue_static7<0, 6>), sgrid, block, 0, stream, a);
+                }
+            } else if (waves == 7) {
+                if (fast) hipLaunchKernelGGL((force_kernel_queue_persist<1, 6>), pgrid, block, 0, stream, a);
+                else hipLaunchKernelGGL((force_kernel_queue_persist<0, 6>), pgrid, block, 0, stream, a);
+            } else if (waves == 6) {
+                if (fast) hipLaunchKernelGGL((force_kernel_queue_persist6<1, 6>), pgrid, block, 0, stream, a);
+                else hipLaunchKernelGGL((force_kernel_queue_persist6<0, 6>), pgrid, block, 0, stream, a);
+            } else {
+                if (fast) hipLaunchKernelGGL((force_kernel_queue_persist5<1, 6>), pgrid, block, 0, stream, a);
+                else hipLaunchKernelGGL((force_kernel_queue_persist5<0, 6>), pgrid, block, 0, stream, a);
+            }
             HIP_TRY(hipGetLastError());
             return PEDONI_OK;
         }
+#endif
         auto launch = [&](auto exact_kernel, auto fast_kernel) {
             if (fast) hipLaunchKernelGGL(fast_kernel, grid, block, 0, stream, a);
             else hipLaunchKernelGGL(exact_kernel, grid, block, 0, stream, a);
@@ -829,8 +852,10 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
             }
             m->force_choice = ForceChoice{s94 ? ForceBuild::S94 : ForceBuild::Default, sl};
         }
+#ifdef PEDONI_DIAGNOSTICS
         const char* fp = std::getenv("PEDONI_FORCE_PERSIST");
-        if (fp) m->force_persist = std::atoi(fp) ? 1 : 0;
+        if (fp) m->force_persist = std::atoi(fp);      // 1 / 7, 6, 5: ticket form at that many waves per SIMD; 15-17: static strides
+#endif
     }
     *out = nullptr;
 

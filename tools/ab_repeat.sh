@@ -3,10 +3,12 @@
 # binary differs from the next by up to +-2.5 % (profiles/r02_ab_sched2.txt), so a change worth 1-2 %
 # only shows in the MEDIAN of alternating runs.
 #   ROUNDS=5 bash tools/ab_repeat.sh TAG "flags of variant 1" "env NAME=VALUE" ...   (variant 0 = the build's own flags;
-#   a variant "env NAME=VALUE ..." is the build's own binary run with that environment)
+#   a variant "env NAME=VALUE ..." is the build's own binary run with that environment; DIAG=1 builds every variant
+#   with -DPEDONI_DIAGNOSTICS, for the switches that exist in the diagnostics build only: PEDONI_FORCE_PERSIST, PEDONI_ABLATE)
 TAG=${1:?tag}; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/abr_$TAG; mkdir -p "$OUT"
-BASE="-O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-memory-clause --offload-arch=gfx950 -shared -fPIC -I$ROOT/include -I$ROOT/pedoni_amd/csrc -I/opt/rocm/include"
+[ -n "$DIAG" ] && DIAGFLAG="-DPEDONI_DIAGNOSTICS"
+BASE="$DIAGFLAG -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-memory-clause --offload-arch=gfx950 -shared -fPIC -I$ROOT/include -I$ROOT/pedoni_amd/csrc -I/opt/rocm/include"
 i=0; N=0
 for FLAGS in "" "$@"; do
     mkdir -p /tmp/abr_$i; cp $ROOT/pedoni_amd/lib/libpedoni_host.so /tmp/abr_$i/
