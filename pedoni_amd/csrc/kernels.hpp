@@ -400,6 +400,15 @@ __device__ __forceinline__ void move_agent(const SoA& a, uint32_t from, uint32_t
     a.skey_out[to] = packed;
 }
 
+// (defined below, beside reorder_kernel)
+__device__ __forceinline__ void reorder_body(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
+                                             GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
+                                             const uint32_t* __restrict__ cs_new,
+                                             const uint32_t* __restrict__ slots,
+                                             const SortFlags* __restrict__ flags, uint32_t parity,
+                                             uint32_t* __restrict__ cell_count, const SoA& a,
+                                             uint32_t first_thread, uint32_t n_threads);
+
 // Per-cell member counts are already in cell_count when the pass starts: every key that is
 // stored -- by the force kernel's tail, by K_KEY or by the halo unpack -- is followed by one
 // integer atomicAdd on its cell.  The scan turned them into cell_start (and zeroed them).
@@ -414,8 +423,16 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
                              uint32_t parity, uint32_t* __restrict__ cell_count, SoA a,
                              uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed,
                              uint32_t* __restrict__ row_count, int32_t row0, int32_t row1,
-                             uint32_t* __restrict__ status, uint32_t* __restrict__ tickets)
+                             uint32_t* __restrict__ status, uint32_t* __restrict__ tickets,
+                             uint32_t* __restrict__ done_count)
 {
+    // `done_count` != null: the host launches NO reorder kernel after this pass (steady state:
+    // nothing appended, not a band) and a general-form pass that only the device knows of -- an agent
+    // that moved more than one cell -- is put in order here, by the workgroup that finishes last:
+    // every workgroup releases its slot writes (agent scope) and counts itself in; the one that
+    // counts last acquires and ranks every cell alone.  Slow and correct, for a case that a finite
+    // state cannot reach (|v| dt <= 0.38 m < one cell); the common tick reads one flag and pays nothing.
+    const bool collect = done_count != nullptr && flags->far[parity] != 0;
     uint32_t j = i0 + xcd_contiguous_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     // the NEXT tick's flag is raised by this tick's update_states and the next K_KEY; it can
     // be cleared here because every key of this tick has been written and nothing reads it now
@@ -431,9 +448,8 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
         // (diagnostics build: the tile tickets of the persistent force kernel that follows this pass)
         if (tickets && threadIdx.x < 8u) tickets[threadIdx.x * TICKET_STRIDE] = 0;
     }
-    if (j >= n_total) return;
-    uint32_t c = key[j];
-    if (c == DEAD) return;
+    const uint32_t c = j < n_total ? key[j] : DEAD;
+    if (c != DEAD) {
     uint32_t cy = c / (uint32_t)grid.cols, cx = c - cy * (uint32_t)grid.cols;
     if (!general_cell(flags, parity, band, (int32_t)cy)) {
         // the agent's own record and its cell's start depend on j and c alone: requested BEFORE the
@@ -465,20 +481,36 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
         if (to < n_total) slots[to] = j;
         else atomicOr(status, STATUS_LIVE_OVERFLOW);
     }
+    }
+    if (collect) {                                     // (uniform over the grid: one flag word)
+        __shared__ uint32_t is_last;
+        __threadfence();                               // release: this workgroup's slots / counters
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t arrived = atomicAdd(done_count, 1u);
+            is_last = arrived + 1u == gridDim.x ? 1u : 0u;
+            if (is_last) *done_count = 0;              // ready for the next pass
+        }
+        __syncthreads();
+        if (is_last) {
+            __threadfence();                           // acquire: every other workgroup's writes
+            reorder_body(key, i0, n_total, grid, band, cs_old, cs_new, slots, flags, parity, cell_count, a,
+                         threadIdx.x, blockDim.x);
+        }
+    }
 }
 
 // ---- K_REORDER (general form only) --------------------------------------------------------
 // sfm.rs:66-75: an agent's place inside its cell is the number of cell-mates with a smaller
 // previous index; the slot list gives those indices in arbitrary (atomic arrival) order.
-__global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
-                               GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
-                               const uint32_t* __restrict__ cs_new,
-                               const uint32_t* __restrict__ slots,
-                               const SortFlags* __restrict__ flags, uint32_t parity,
-                               uint32_t* __restrict__ cell_count, SoA a)
+__device__ __forceinline__ void reorder_body(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
+                                             GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
+                                             const uint32_t* __restrict__ cs_new,
+                                             const uint32_t* __restrict__ slots,
+                                             const SortFlags* __restrict__ flags, uint32_t parity,
+                                             uint32_t* __restrict__ cell_count, const SoA& a,
+                                             uint32_t first_thread, uint32_t n_threads)
 {
-    // launched with a small fixed grid: in the common tick (gather form everywhere) every
-    // wave leaves after one flag read
     const bool everything = flags->far[parity] != 0;
     if (!everything && !band.sharded) return;
     // sharded, no far mover: only agents landing in the four boundary rows are in general
@@ -491,8 +523,7 @@ __global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, ui
         if (skip_end < skip_begin) skip_end = skip_begin;
     }
     const uint32_t skipped = skip_end - skip_begin;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_total - i0 - skipped;
-         t += gridDim.x * blockDim.x) {
+    for (uint32_t t = first_thread; t < n_total - i0 - skipped; t += n_threads) {
         uint32_t i = i0 + t;
         if (i >= skip_begin) i += skipped;
         uint32_t k = key[i];
@@ -505,6 +536,19 @@ __global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, ui
         if (base + before < n_total) move_agent(a, i, base + before, pack_cell(cx, cy));
         cell_count[k] = 0;   // the provisional-slot counter, back to zero for the next tick's counts
     }
+}
+
+__global__ void reorder_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
+                               GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
+                               const uint32_t* __restrict__ cs_new,
+                               const uint32_t* __restrict__ slots,
+                               const SortFlags* __restrict__ flags, uint32_t parity,
+                               uint32_t* __restrict__ cell_count, SoA a)
+{
+    // grid-stride; launched only when the host knows the pass (or, for a band, its boundary rows) is in
+    // general form -- see place_kernel's `inline_reorder` for the case only the device knows of
+    reorder_body(key, i0, n_total, grid, band, cs_old, cs_new, slots, flags, parity, cell_count, a,
+                 blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // no-grid compaction: survivor i goes to its exclusive flag prefix

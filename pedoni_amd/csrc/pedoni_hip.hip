@@ -135,7 +135,8 @@ struct PedoniModel {
     uint32_t* d_block_sums = nullptr;
     uint32_t block_sums_cap = 0;
     uint32_t* d_row_count = nullptr; // members per grid row (top level of the row scan)
-    uint32_t* d_tickets = nullptr;   // 8 tile-ticket words of the persistent force kernel, TICKET_STRIDE apart
+    uint32_t* d_tickets = nullptr;   // [8 * TICKET_STRIDE] = place_kernel's workgroups-done counter; in front of it, the
+                                     // diagnostics build's 8 tile-ticket words, TICKET_STRIDE apart
     bool tickets_fresh = false;      // zeroed by the place kernel and not drawn from since
     int force_persist = -1;          // PEDONI_FORCE_PERSIST: 0 never, 1 / 7, 6, 5 = the persistent form at that residency; -1 = by size
     uint32_t* d_live = nullptr; // device: [0] live agent count (absolute end index), [1] sticky status word
@@ -387,10 +388,16 @@ int sort_despawn(PedoniModel* m)
         SoA soa{m->d_pos[src], m->d_velx[src], m->d_dest[vsrc],
                 m->d_pos[dst], m->d_velx[dst], m->d_dest[vdst], m->d_skey[sk_new],
                 m->opt.math_mode == PEDONI_MATH_FAST ? 1 : 0};
-        {
+        // K_KEY only when something needs a key: every stored agent (first pass, general form), or the
+        // agents stored since the last update (appended, exchanged).  A steady-state tick launches
+        // nothing here -- and records no event pair for it either.
+        const bool key_all = !m->keys_valid || force_general;
+        const bool key_halo = !key_all && m->halo_cap && !m->halo_keys_done;
+        const bool key_appended = !key_all && n_total > m->gap_end && !m->halo_keys_done;
+        if (key_all || key_halo || key_appended) {
             Timed t(m, PEDONI_K_BIN);
             if (t.rc) return t.rc;
-            if (!m->keys_valid || force_general) {
+            if (key_all) {
                 // every stored agent needs its key (and its cell's count: drop what a fused
                 // update may already have accumulated for keys that are now recomputed)
                 if (m->counts_dirty) {
@@ -407,13 +414,13 @@ int sort_despawn(PedoniModel* m)
             } else {
                 // own agents got their keys (and counts) from the last update_states; only agents
                 // stored since then are keyed here (exchanged lists: by halo_unpack_kernel)
-                if (m->halo_cap && !m->halo_keys_done)
+                if (key_halo)
                     hipLaunchKernelGGL(key_kernel, dim3(blocks_for(m->halo_cap, bs)), dim3(bs), 0,
                                        m->stream, m->d_pos[src], m->d_dest[vsrc], i0, m->base, m->base,
                                        m->d_live, m->gap_end, m->d_halo, m->field, m->grid, m->band_lo,
                                        m->band_hi, m->d_skey[sk_old], 0, parity, m->d_flags, m->d_key,
                                        m->d_scan_in, m->d_row_count);
-                if (n_total > m->gap_end && !m->halo_keys_done)
+                if (key_appended)
                     hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n_total - m->gap_end, bs)), dim3(bs),
                                        0, m->stream, m->d_pos[src], m->d_dest[vsrc], m->gap_end, n_total,
                                        m->base, m->d_live, m->gap_end, m->d_halo, m->field, m->grid,
@@ -423,6 +430,14 @@ int sort_despawn(PedoniModel* m)
         }
         TRY(run_row_scan(m, row0, row1, m->d_cs[cs_new], n_total));
         m->counts_dirty = false;
+        // The reorder launch (general form: in-cell order by previous index) is needed when the host
+        // KNOWS agents take the general form: first pass / forced, agents stored since the last update
+        // (their keys raise the device flag), a band's boundary rows, device spawning.  Otherwise --
+        // the steady-state tick -- it is not launched at all (it used to be: a 128-block kernel that read
+        // one flag and left, 5-6 us per tick), and place_kernel's last workgroup covers the one case
+        // only the device can know of (an agent that moved more than one cell).
+        const bool host_knows_general = force_general || n_total > m->gap_end || m->halo_cap != 0 || m->n_spawners != 0 ||
+                                        m->halo_keys_done;
         {
             Timed t(m, PEDONI_K_SLOT);
             if (t.rc) return t.rc;
@@ -430,17 +445,15 @@ int sort_despawn(PedoniModel* m)
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
                                m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
                                (m->halo_cap || m->n_spawners) ? m->d_halo : nullptr, m->d_row_count, row0,
-                               row1, m->d_live + 1, m->force_persist > 0 ? m->d_tickets : nullptr);
+                               row1, m->d_live + 1, m->force_persist > 0 ? m->d_tickets : nullptr,
+                               host_knows_general ? nullptr : m->d_tickets + 8 * TICKET_STRIDE);
             m->tickets_fresh = true;
         }
-        {
+        if (host_knows_general) {
             Timed t(m, PEDONI_K_REORDER);
             if (t.rc) return t.rc;
-            // grid-stride kernel.  A steady-state tick has nothing (or, for a band, only the agents
-            // of its four boundary rows) in general form and every surplus block costs dispatch
-            // time (1024 blocks that leave after one flag read: 4.5 us), so the grid is small
-            // unless the host already knows the whole pass is in general form; a far mover found
-            // by the device alone is reordered by the small grid, correctly and slowly.
+            // grid-stride kernel: a band in steady state has only the agents of its four boundary rows in
+            // general form (small grid); a whole pass in general form gets the full grid
             const uint32_t reorder_blocks = std::min(blocks_for(n_threads, bs), force_general ? 1024u : 128u);
             hipLaunchKernelGGL(reorder_kernel, dim3(reorder_blocks), dim3(bs), 0,
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
@@ -929,8 +942,8 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
         }
         C_TRY(dev_alloc(&m->d_row_count, (size_t)m->grid.rows + 1));
         C_HIP(hipMemset(m->d_row_count, 0, ((size_t)m->grid.rows + 1) * sizeof(uint32_t)));
-        C_TRY(dev_alloc(&m->d_tickets, (size_t)8 * TICKET_STRIDE));
-        C_HIP(hipMemset(m->d_tickets, 0, (size_t)8 * TICKET_STRIDE * sizeof(uint32_t)));
+        C_TRY(dev_alloc(&m->d_tickets, (size_t)9 * TICKET_STRIDE));     // + place_kernel's workgroups-done counter
+        C_HIP(hipMemset(m->d_tickets, 0, (size_t)9 * TICKET_STRIDE * sizeof(uint32_t)));
     }
     m->band_lo = 0;
     m->band_hi = opt->use_neighbor_grid ? m->grid.rows : 0;
