@@ -31,7 +31,9 @@ class _Options(C.Structure):
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
-        so = _DIR / "libpedoni_oracle.so"
+        import os
+        # PEDONI_ORACLE_LIB: another build of the same sources (the sanitizer build of `make asan`)
+        so = Path(os.environ["PEDONI_ORACLE_LIB"]) if os.environ.get("PEDONI_ORACLE_LIB") else _DIR / "libpedoni_oracle.so"
         if not so.exists():
             subprocess.run(["make", "-s", "-C", str(_DIR)], check=True)
         L = C.CDLL(str(so))

@@ -8,6 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -72,6 +74,42 @@ struct Rng {
 struct EventPair {
     hipEvent_t a, b;
     int kernel;
+};
+
+// ---- roctx ranges (the reference brackets spawn / update with Instant::now, lib.rs:68-91) ---
+// PEDONI_ROCTX=1: every pass and every kernel launch of a tick is bracketed by a named roctx range, so
+// a `rocprofv3 --marker-trace --kernel-trace` timeline shows the tick's structure (tools/roctx_trace.sh).
+// The marker library is resolved with dlopen on first use and only then: without the switch (the
+// default) not one call is made and nothing is loaded.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+const Roctx& roctx()
+{
+    static const Roctx api = [] {
+        Roctx r;
+        const char* on = std::getenv("PEDONI_ROCTX");
+        if (!on || on[0] != '1') return r;
+        for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                r.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+                r.pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (r.push && r.pop) return r;
+                r = Roctx{};
+            }
+        }
+        std::fprintf(stderr, "pedoni_hip: PEDONI_ROCTX=1 but no roctx library could be loaded; ranges are off\n");
+        return r;
+    }();
+    return api;
+}
+struct Range {
+    bool on;
+    explicit Range(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~Range() { if (on) roctx().pop(); }
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
 };
 
 } // namespace
@@ -218,7 +256,8 @@ struct Timed {
     PedoniModel* m;
     EventPair* ep = nullptr;
     int rc = PEDONI_OK;
-    Timed(PedoniModel* m_, int kernel) : m(m_)
+    Range range;
+    Timed(PedoniModel* m_, int kernel) : m(m_), range(kernel >= 0 ? KERNEL_NAMES[kernel] : "force_integrate (side stream)")
     {
         if (kernel < 0 || !m->profile_now || !((m->profile_mask >> kernel) & 1u)) return;
         if (m->ev_used == m->ev_pool.size()) {
@@ -361,6 +400,7 @@ inline uint32_t blocks_for(uint32_t n, uint32_t bs) { return std::max(1u, (n + b
 // sfm.rs:58-88 on the device
 int sort_despawn(PedoniModel* m)
 {
+    Range pass("spawn_pedestrians: sort/despawn pass (sfm.rs:58-88)");
     uint32_t n_total = m->n_upper;
     const uint32_t i0 = m->base - m->halo_cap;     // first index a pass may have to look at
     const uint32_t n_threads = n_total - i0;
@@ -668,6 +708,7 @@ int update_states(PedoniModel* m)
         return fail(PEDONI_E_INVALID,
                     "update_states needs the sort/despawn pass of spawn_pedestrians first "
                     "(Simulator::tick order, lib.rs:85,90)");
+    Range pass("update_states (sfm.rs:91-255)");
     TRY(launch_force(m, nullptr));
     after_update(m);
     return PEDONI_OK;
@@ -1107,7 +1148,10 @@ int tick_graph_pair(PedoniModel* m)
         m->graph_cs = cs; m->graph_sk = sk; m->graph_parity = parity; m->graph_stream = m->stream;
         m->graph_valid = true;
     }
-    HIP_TRY(hipGraphLaunch(m->graph_exec, m->stream));
+    {
+        Range replay("tick pair (captured graph replay)");
+        HIP_TRY(hipGraphLaunch(m->graph_exec, m->stream));
+    }
     // host state after a pair of ticks == before it (see above); the flags the eager path
     // would have left: keys fused, counts pending, order not sorted
     m->keys_valid = true;

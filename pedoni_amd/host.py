@@ -56,7 +56,10 @@ class SimulatorOptions:
 
 
 def library_path() -> Path:
-    return abi.library_path().with_name("libpedoni_host.so")
+    # PEDONI_HOST_LIB: another build of the SAME library (the sanitizer build of `make asan`)
+    import os
+    override = os.environ.get("PEDONI_HOST_LIB")
+    return Path(override) if override else abi.library_path().with_name("libpedoni_host.so")
 
 
 def load_library() -> C.CDLL:
