@@ -1040,6 +1040,237 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
     force_queue_tile<MODE, SLOTS, TRACE, ABL>(a, block * blockDim.x + threadIdx.x, queue_all[wave], who_all[wave], tab);
 }
 
+// ---- K_FORCE for SMALL crowds: G lanes per agent ----------------------------
+// With ~1e5 agents (BASELINE C2) the one-lane-per-agent kernel puts one or two waves on a SIMD and
+// its launch lasts as long as its HEAVIEST wave: a wave is as slow as its fullest lane (70 candidate
+// slots in C2's densest cells), and nothing else is there to run meanwhile.  Here a wave owns 64 / G
+// agents and the G lanes of an agent share its work:
+//   phase 1  lane g of the group tests the candidate slots s = g, g + G, g + 2 G ... (the fullest
+//            lane's walk is G times shorter); survivors go to the same per-wave queue.
+//   phase 2  unchanged: the queue is drained 64 pairs at a time whoever queued them.
+//   phase 3  every lane of the group forms the SAME ordered sum: for each batch position k the
+//            group's G results are taken in slot order g = 0 .. G-1 from the neighbouring lanes by
+//            DPP (quad_perm, no LDS traffic) -- acc += f(slot G k), acc += f(slot G k + 1), ... --
+//            exactly the reference's `acc += force` sequence (sfm.rs:153), so the bits are the
+//            one-lane kernel's.  A slot without a pair contributes -0 (x + (-0) == x for every x).
+// Everything else -- the agent's loads, both stencils, the integrator, the next key -- is computed
+// by all G lanes alike (same inputs, same results); lane 0 of the group stores and counts.  G times
+// the waves, each with a G times shorter critical path: the crowd's makespan, not its instruction
+// count, is what a small launch pays for.
+template <int G> __device__ __forceinline__ float group_lane(float v, int g)
+{
+    // value of lane g of this lane's group (G = 2: pairs inside a quad; G = 4: the quad)
+    static_assert(G == 2 || G == 4, "groups of 2 or 4 lanes");
+    int r;
+    const int x = __float_as_int(v);
+    if constexpr (G == 4) {
+        switch (g) {
+        case 0: r = __builtin_amdgcn_mov_dpp(x, 0x00, 0xf, 0xf, true); break;   // quad_perm:[0,0,0,0]
+        case 1: r = __builtin_amdgcn_mov_dpp(x, 0x55, 0xf, 0xf, true); break;   // [1,1,1,1]
+        case 2: r = __builtin_amdgcn_mov_dpp(x, 0xaa, 0xf, 0xf, true); break;   // [2,2,2,2]
+        default: r = __builtin_amdgcn_mov_dpp(x, 0xff, 0xf, 0xf, true); break;  // [3,3,3,3]
+        }
+    } else {
+        if (g == 0) r = __builtin_amdgcn_mov_dpp(x, 0xa0, 0xf, 0xf, true);      // [0,0,2,2]
+        else r = __builtin_amdgcn_mov_dpp(x, 0xf5, 0xf, 0xf, true);             // [1,1,3,3]
+    }
+    return __int_as_float(r);
+}
+
+template <int MODE, int SLOTS, int G>
+__device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const uint32_t tile, float2* __restrict__ queue,
+                                                       uint32_t* __restrict__ who, const uint64_t* __restrict__ tab)
+{
+    constexpr uint32_t PER_WAVE = 64u / (uint32_t)G;
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & (uint32_t)(G - 1);
+    const uint32_t id = a.base + tile * PER_WAVE + lane / (uint32_t)G;
+    const uint32_t n = *a.live_count;
+    const bool valid = id < n;
+    const bool writer = sub == 0;                 // the group's lane that stores and counts
+
+    v2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), acc = mk(0.0f, 0.0f), e = mk(0.0f, 0.0f), wall = mk(0.0f, 0.0f);
+    float4 vv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float desired_speed = 0.0f;
+    uint32_t r0 = 0, r1 = 0, r2 = 0, n0 = 0, n1 = 0, n2 = 0;
+    bool ghost = false;
+    int32_t ix = 0, iy = 0;
+    if (valid) {
+        float2 p = a.pos[id];
+        vv = a.velx[id];
+        pos = mk(p.x, p.y);
+        vel = mk(vv.x, vv.y);
+        desired_speed = vv.w;
+        uint32_t destination = a.dest[id];
+        ix = f32_as_i32(pos.x / a.grid.unit);                    // sfm.rs:113
+        iy = f32_as_i32(pos.y / a.grid.unit);
+        ghost = iy < a.band_lo || iy >= a.band_hi;
+        if (!ghost) {
+            // ONE stencil evaluation per lane: lane 1 of the group samples the distance map (the wall
+            // force, sfm.rs:188-192), the others the agent's potential map (the goal direction,
+            // :107-108) -- the same 4 x 4 patch code on a different map pointer, so the two stencils of
+            // an agent run side by side instead of one after the other.  Both results are then
+            // handed round the group by DPP.  (The explicit-segment wall path stays in the epilogue.)
+            const bool wall_lane = sub == 1 && a.use_distance_map;
+            const float* map = wall_lane ? a.field.distance_map
+                                         : (destination < a.field.n_maps ? a.field.potential_maps[destination] : a.field.distance_map);
+            const v2 q = field_coord(a.field, pos);
+            float centre;
+            const v2 g = sobel_fast(map, dims_of(a.field), q.x, q.y, &centre);
+            const v2 e_mine = normalize<0>(g);                                        // goal lanes (exact in both modes)
+            const v2 w_dir = -normalize<MODE>(g);                                     // wall lane: obstacle_force_map
+            const float w_k = (10.0f * 0.2f) * fexp<MODE>(div_02<MODE>(-centre), tab);
+            e = mk(group_lane<G>(e_mine.x, 0), group_lane<G>(e_mine.y, 0));
+            wall = mk(group_lane<G>(w_dir.x * w_k, 1), group_lane<G>(w_dir.y * w_k, 1));
+            acc = acc + vdiv<MODE>(e * desired_speed - vel, 0.5f); // :109
+            int32_t y_start = max(iy - 1, 0), y_end = min(iy + 1, a.grid.rows - 1); // :117-118
+            int32_t x_start = max(ix - 1, 0), x_end = min(ix + 1, a.grid.cols - 1); // :119-120
+            for (int32_t y = y_start, k = 0; y <= y_end; ++y, ++k) {
+                int64_t offset = (int64_t)y * a.grid.cols;
+                uint32_t i_start = a.cell_start[offset + x_start];
+                uint32_t i_end = a.cell_start[offset + x_end + 1];
+                if (k == 0) { r0 = i_start; n0 = i_end - i_start; }
+                else if (k == 1) { r1 = i_start; n1 = i_end - i_start; }
+                else { r2 = i_start; n2 = i_end - i_start; }
+            }
+        }
+    }
+    const uint32_t cnt = n0 + n1 + n2;            // the agent's candidates: the same on all G lanes
+    uint32_t max_cnt = cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, off, 64));
+    max_cnt = __builtin_amdgcn_readfirstlane(max_cnt);
+    const uint32_t n01 = n0 + n1, r1s = r1 - n0, r2s = r2 - n01;
+    const uint32_t id_safe = valid ? id : a.base;
+
+    // one batch = SLOTS slots per lane = G * SLOTS consecutive slots of the agent
+    for (uint32_t base = 0; base < max_cnt; base += (uint32_t)(G * SLOTS)) {
+        // ---- phase 1: this lane's share of the batch: slots base + sub, base + sub + G, ... ----
+        uint32_t qlen = 0;
+        uint32_t at_of[SLOTS];
+        uint32_t idx[SLOTS];
+        float2 d[SLOTS];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            uint32_t s = base + (uint32_t)(k * G) + sub;
+            uint32_t i = s + (s < n0 ? r0 : (s < n01 ? r1s : r2s));
+            idx[k] = s < cnt ? i : id_safe;
+            d[k] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.pos) + (idx[k] << 3));
+        }
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            float dx = pos.x - d[k].x;                            // :131
+            float dy = pos.y - d[k].y;
+            float d2 = (dx * dx) + (dy * dy);                     // :132
+            unsigned long long m_near, m_other;
+            asm("v_cmp_nlt_f32_e64 %0, 4.0, %1" : "=s"(m_near) : "v"(d2));            // !(d2 > 4): NaN passes, as upstream
+            asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(m_other) : "v"(idx[k]), "v"(id_safe));
+            const unsigned long long mask = m_near & m_other;
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            uint32_t at;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(at) : "v"((uint32_t)(SLOTS * 64) + lane), "v"(qlen + before), "s"(mask));
+            at_of[k] = at;
+            queue[at] = make_float2(dx, dy);
+            who[at] = idx[k] | (lane << 26);
+            qlen += (uint32_t)__popcll(mask);
+        }
+        queue[(uint32_t)(SLOTS * 64) + lane] = make_float2(-0.0f, -0.0f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase 2: one pair force per lane (as in the one-lane kernel) ---------------------
+        for (uint32_t q0 = 0; q0 < qlen; q0 += 64) {
+            uint32_t q = q0 + lane;
+            const bool busy = q < qlen;
+            const uint32_t w = busy ? who[q] : (id_safe | (lane << 26));
+            const float4 vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.velx) + ((w & 0x03ffffffu) << 4));
+            const int own = (int)(w >> 26);
+            const float eo_x = __shfl(e.x, own, 64), eo_y = __shfl(e.y, own, 64);
+            if (busy) {
+                float2 en = queue[q];
+                v2 f = pair_force_value<MODE>(mk(en.x, en.y), mk(eo_x, eo_y), mk(vn.x, vn.y), vn.z, tab);
+                queue[q] = make_float2(f.x, f.y);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase 3: the group's ordered sum, formed alike on each of its lanes (sfm.rs:153) ----
+        float2 fr[SLOTS];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) fr[k] = queue[at_of[k]];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)           // slot base + k G + g was lane g's k-th
+                acc = acc + mk(group_lane<G>(fr[k].x, g), group_lane<G>(fr[k].y, g));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (!valid) {
+        // slot of a despawned agent (whole-array launches only)
+        if (writer && a.key_next && id < a.key_end) a.key_next[id] = DEAD;
+        return;
+    }
+    if (ghost) {                                                  // ghost row: never integrated
+        if (writer && a.pos_out) {
+            float qn = __builtin_nanf("");
+            a.pos_out[id] = make_float2(qn, qn);
+            a.velx_out[id] = vv;
+            if (a.key_next) a.key_next[id] = DEAD;
+        }
+        return;
+    }
+    uint32_t dest_k = 0;
+    const float* map_k = nullptr;
+    if (a.key_next) {
+        dest_k = a.dest[id];
+        map_k = dest_k < a.field.n_maps ? a.field.potential_maps[dest_k] : nullptr;
+    }
+    if (a.use_distance_map) acc = acc + wall;                     // (= obstacle_force_map: direction * k, lane 1's)
+    else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
+
+    if (a.acc_out) { if (writer) a.acc_out[id] = make_float2(acc.x, acc.y); return; }
+
+    // integrator, sfm.rs:245-254
+    v2 vel_prev = vel;
+    vel = vel + acc * 0.1f;
+    float max_len = desired_speed * 1.3f;
+    float length_sq = dot(vel, vel);
+    if (length_sq > max_len * max_len) {                          // glam clamp_length_max
+        v2 q = vdiv<MODE>(vel, fsqrt<MODE>(length_sq));
+        vel = mk(max_len * q.x, max_len * q.y);
+    }
+    pos = pos + (vel + vel_prev) * 0.05f;
+    if (writer) {
+        a.pos_out[id] = make_float2(pos.x, pos.y);
+        a.velx_out[id] = make_float4(vel.x, vel.y, 0.0f, desired_speed);
+    }
+    if (a.key_next) {
+        uint32_t k = DEAD;
+        int32_t cx = 0, cy = 0;
+        const v2 qk = field_coord(a.field, pos);
+        if (cell_xy(a.grid, pos, cx, cy) && cy >= a.band_lo - 1 && cy <= a.band_hi &&
+            (map_k && bilinear(map_k, dims_of(a.field), qk.x, qk.y) > 0.25f)) {
+            k = (uint32_t)cy * (uint32_t)a.grid.cols + (uint32_t)cx;
+            if (writer && (abs(cx - ix) > 1 || abs(cy - iy) > 1)) atomicOr(&a.flags->far[a.parity_next], 1u);
+        }
+        if (writer) a.key_next[id] = k;
+        count_key(a.cell_count, a.row_count, writer && k != DEAD, k, (uint32_t)cy);
+    }
+}
+
+template <int MODE, int SLOTS, int G>
+__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_group(ForceArgs a)
+{
+    PEDONI_FORCE_LDS(SLOTS);
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    force_queue_tile_group<MODE, SLOTS, G>(a, block * FORCE_WAVES + wave, queue_all[wave], who_all[wave], tab);
+}
+
 #ifdef PEDONI_DIAGNOSTICS
 // diagnostic build of the 7-wave kernel with the extended ablation switches (PEDONI_ABLATE bits 8
 // and up; tools/ablate_launch.py): a build of its own, so that the product kernels carry none of it

@@ -206,6 +206,8 @@ struct PedoniModel {
     bool xcd_remap = true;     // PEDONI_NO_XCD_REMAP=1: hardware block order
     unsigned long long* d_trace = nullptr; // PEDONI_FORCE_TRACE=1: per-phase cycle sums of the force kernel
     ForceChoice force_choice{}; // PEDONI_FORCE_KERNEL: build and queue depth of the force kernel (unset = by size)
+    int force_group = -1;       // PEDONI_FORCE_GROUP: lanes per agent of the force kernel (1, 2, 4; unset = by size)
+    int force_group_slots = 0;  // PEDONI_FORCE_GROUP_SLOTS: queue depth of the group kernel (4, 6, 8; unset = 6)
 
     // steady-state tick pair captured as a hipGraph (pedoni_hip_tick_n); see tick_graph()
     hipGraphExec_t graph_exec = nullptr;
@@ -396,6 +398,15 @@ int run_row_scan(PedoniModel* m, int32_t row0, int32_t row1, uint32_t* out, uint
 }
 
 inline uint32_t blocks_for(uint32_t n, uint32_t bs) { return std::max(1u, (n + bs - 1) / bs); }
+
+// Lanes per agent of the force kernel by crowd size (kernels.hpp force_kernel_queue_group), from
+// tools/group_n_sweep.sh on MI355X (profiles/r03_group_n_sweep.txt; tick, us, G = 1 / 2 / 4):
+// N = 25 000: 34.2 / 27.1 / 24.7; 50 000: 34.7 / 28.6 / 29.1; 1e5: 34.1 / 32.0 / 34.9; 2e5: 43.6 / 42.8 / 47.9;
+// 3e5: 50.7 / 52.0 / 61.3 (rho = 1); rho = 2.5: 1e5: 51.1 / 46.7 / 46.7, 3e5: 81.3 / 76.5 / 82.1.
+// Small launches are bound by their heaviest wave's critical path, which the group form shortens;
+// from ~3e5 agents on the SIMDs are busy and the group's redundant per-agent work costs more than
+// the shorter path brings.
+inline int group_by_size(uint32_t n) { return n < 40000u ? 4 : (n < 250000u ? 2 : 1); }
 
 // sfm.rs:58-88 on the device
 int sort_despawn(PedoniModel* m)
@@ -668,6 +679,24 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
             if (fast) hipLaunchKernelGGL(fast_kernel, grid, block, 0, stream, a);
             else hipLaunchKernelGGL(exact_kernel, grid, block, 0, stream, a);
         };
+        // small crowds: G lanes per agent (kernels.hpp force_kernel_queue_group) -- whole-array launches only
+        int group = m->force_group > 0 ? m->force_group : group_by_size(n);
+        if (part != 0 || m->force_choice.build != ForceBuild::BySize) group = 1;
+        if (group > 1) {
+            grid = dim3(blocks_for(n, FORCE_THREADS / (uint32_t)group));
+            const int gs = m->force_group_slots ? m->force_group_slots : (group == 2 ? 8 : 6);   // (C2: 8 slots 49.9 us, 6 slots 50.5)
+            if (group == 2) {
+                if (gs == 8) launch(force_kernel_queue_group<0, 8, 2>, force_kernel_queue_group<1, 8, 2>);
+                else if (gs == 4) launch(force_kernel_queue_group<0, 4, 2>, force_kernel_queue_group<1, 4, 2>);
+                else launch(force_kernel_queue_group<0, 6, 2>, force_kernel_queue_group<1, 6, 2>);
+            } else {
+                if (gs == 8) launch(force_kernel_queue_group<0, 8, 4>, force_kernel_queue_group<1, 8, 4>);
+                else if (gs == 4) launch(force_kernel_queue_group<0, 4, 4>, force_kernel_queue_group<1, 4, 4>);
+                else launch(force_kernel_queue_group<0, 6, 4>, force_kernel_queue_group<1, 6, 4>);
+            }
+            HIP_TRY(hipGetLastError());
+            return PEDONI_OK;
+        }
         if (c.build == ForceBuild::S94) {
             switch (c.slots) {
             case 4: launch(force_kernel_queue_s94<0, 4>, force_kernel_queue_s94<1, 4>); break;
@@ -893,6 +922,14 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
         }
         const char* ng = std::getenv("PEDONI_NO_GRAPH");
         m->use_graph = !(ng && ng[0] == '1');
+        if (const char* fg = std::getenv("PEDONI_FORCE_GROUP")) {
+            m->force_group = std::atoi(fg);
+            if (m->force_group != 1 && m->force_group != 2 && m->force_group != 4) {
+                pedoni_hip_destroy(m);
+                return fail(PEDONI_E_INVALID, "create: PEDONI_FORCE_GROUP must be 1, 2 or 4");
+            }
+        }
+        if (const char* fgs = std::getenv("PEDONI_FORCE_GROUP_SLOTS")) m->force_group_slots = std::atoi(fgs);
         if (const char* fk = std::getenv("PEDONI_FORCE_KERNEL")) {
             const std::string v(fk);
             const size_t colon = v.find(':');
