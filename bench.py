@@ -255,14 +255,14 @@ VALU_CYCLES_PER_INST = 2.0
 N_SIMDS = 1024
 
 
-def valu_floor(avg_launch_ms: float, workload_key: str, agents: float, fast: bool):
+def valu_floor(avg_launch_ms: float, workload_key: str, agents: float, kernel_symbol: str, agents_per_wave: int = 64):
     """Instruction-issue floor of the force kernel from the newest committed stall-counter profile
-    of THIS workload and math mode (profiles/*_stalls.json, tools/profile_stalls.sh /
-    profile_workload.sh): VALU wave-instructions PER WAVE of the profiled launches x the waves of
-    this run's launch (64 agents each) x 2 cycles / 1024 SIMDs, at the clock the profiled launches
-    held.  (Round 2 applied a 1e6-agent profile's launch total to any run: 8x off at 8e6 agents.)"""
+    of THIS workload taken on THE KERNEL THE RUN LAUNCHES (profiles/*_stalls.json, tools/profile_stalls.sh /
+    profile_workload.sh; the symbol comes from pedoni_hip_force_kernel_info): VALU wave-instructions
+    PER WAVE of the profiled launches x the waves of this run's launch x 2 cycles / 1024 SIMDs, at the
+    clock the profiled launches held.  None when no profile of that kernel exists.  (Round 2 applied a
+    1e6-agent profile's launch total to any run: 8x off at 8e6 agents.)"""
     best = None
-    want = "<1," if fast else "<0,"
     for p in sorted((ROOT / "profiles").glob("*_stalls.json"), key=_by_age):             # oldest first
         if _profile_workload(p.name) != workload_key or "_base_" in p.name:
             continue
@@ -271,13 +271,12 @@ def valu_floor(avg_launch_ms: float, workload_key: str, agents: float, fast: boo
         except Exception:
             continue
         for k, v in d.items():
-            if "force_kernel" in k and want in k and "trace" not in k and "ablate" not in k \
-                    and v.get("SQ_INSTS_VALU") and v.get("SQ_WAVES"):
+            if k.split("::")[-1] == kernel_symbol and v.get("SQ_INSTS_VALU") and v.get("SQ_WAVES"):
                 best = (v, p.name, k)
     if not best:
         return None
     v, tag, symbol = best
-    waves = float(int((agents + 63) // 64))
+    waves = float(int((agents + agents_per_wave - 1) // agents_per_wave))
     per_wave = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
     insts = per_wave * waves
     floor_cycles = insts * VALU_CYCLES_PER_INST / N_SIMDS
@@ -630,7 +629,8 @@ def main() -> None:
             avg_ms = fk["total_ms"] / fk["launches"]
             achieved = BYTES_FORCE * agents_local / (avg_ms * 1e-3) / 1e9
             traffic, traffic_tag = pmc_traffic(args.workload) if G == 1 and n_per in (100_000, 1_000_000) else (None, None)
-            valu = valu_floor(avg_ms, args.workload, agents_local, args.math == "fast") if G == 1 else None
+            ksym, per_wave = model.force_kernel_info(int(agents_local))
+            valu = valu_floor(avg_ms, args.workload, agents_local, ksym, per_wave) if G == 1 else None
             hbm_frac = achieved / HBM_PEAK_GBS
             out["roofline"] = {
                 # the roof the kernel is closer to: HBM bytes at 8 TB/s, or VALU issue at one
@@ -648,7 +648,7 @@ def main() -> None:
                                  "fabric-side bytes, Infinity-Cache hits included (not HBM bytes proper); the 2x FETCH_SIZE read "
                                  "correction is calibrated on 16 B/lane streams, this kernel's reads are 4-16 B gathers "
                                  "(profiles/r03_gather_traffic.txt)") if traffic else None,
-                "kernel": "force_integrate", "avg_launch_ms": avg_ms,
+                "kernel": "force_integrate", "kernel_symbol": ksym, "avg_launch_ms": avg_ms,
                 "timed_launches": fk["launches"],
                 "algorithmic_bytes_per_launch": BYTES_FORCE * agents_local,
                 "valu": valu,

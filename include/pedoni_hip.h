@@ -293,6 +293,14 @@ int pedoni_shard_set_rebalance(PedoniShard* s, uint32_t every_ticks, uint32_t ma
  * lockstep. */
 int pedoni_shard_local_group_tick_n(PedoniShard** shards, uint32_t n_shards, uint32_t steps);
 
+/* [ext] which instantiation of the force kernel a whole-array launch over `n_agents` agents of this
+ * model takes -- its symbol as rocprofv3 prints it, e.g. "force_kernel_queue_s94<0, 6>" from 4e5
+ * agents up, "force_kernel_queue_group<0, 8, 2>" (2 lanes per agent) for small crowds -- and how
+ * many agents one wave of it owns.  bench.py prices a run's instruction issue with the committed
+ * counter profile of exactly that kernel. */
+int pedoni_hip_force_kernel_info(PedoniModel* m, uint32_t n_agents, char* name, uint32_t name_cap,
+                                 uint32_t* agents_per_wave);
+
 /* [ext] opt-in GPU builder of the field maps (no bit parity with upstream's
  * heap fast marching, field.rs:118-192, whose numbers depend on its pop order): solves
  * |grad u| = f on a rows x cols grid by a block fast iterative method on the first-order upwind

@@ -39,7 +39,7 @@ SYMBOLS = [
     "pedoni_hip_halo_tick_begin", "pedoni_hip_halo_tick_end",
     "pedoni_hip_owned_count",
     "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_selftest_field", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
-    "pedoni_hip_profile_every",
+    "pedoni_hip_profile_every", "pedoni_hip_force_kernel_info",
     "pedoni_hip_create_rows", "pedoni_shard_map_rows", "pedoni_hip_eikonal",
     "pedoni_shard_unique_id", "pedoni_shard_balanced_bounds", "pedoni_shard_recut_bounds", "pedoni_shard_create", "pedoni_shard_destroy",
     "pedoni_shard_begin", "pedoni_shard_tick_n", "pedoni_shard_owned_count", "pedoni_shard_band",
@@ -440,6 +440,14 @@ class HipModel:
         c = C.c_int32(0)
         _check(self._lib, self._lib.pedoni_hip_owned_count(self._h, C.byref(c)))
         return int(c.value)
+
+    def force_kernel_info(self, n_agents: int):
+        """(symbol of the force kernel a whole-array launch over n_agents takes, agents per wave)."""
+        buf = C.create_string_buffer(128)
+        per = C.c_uint32(0)
+        _check(self._lib, self._lib.pedoni_hip_force_kernel_info(self._h, C.c_uint32(n_agents), buf, C.c_uint32(128),
+                                                                 C.byref(per)))
+        return buf.value.decode(), int(per.value)
 
     def debug_force_trace(self, reset: bool = True):
         """Per-phase cycle sums of the instrumented force kernel (PEDONI_FORCE_TRACE=1)."""

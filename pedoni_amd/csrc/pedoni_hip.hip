@@ -399,6 +399,31 @@ int run_row_scan(PedoniModel* m, int32_t row0, int32_t row1, uint32_t* out, uint
 
 inline uint32_t blocks_for(uint32_t n, uint32_t bs) { return std::max(1u, (n + bs - 1) / bs); }
 
+// Which instantiation of the grid-path force kernel a launch over n agents takes: lanes per agent
+// (group), build, queue depth.  One place for the rule; launch_force follows it and
+// pedoni_hip_force_kernel_info reports it (bench.py prices a run with the profile of THAT kernel).
+struct ForcePlan { int group; ForceBuild build; int slots; };
+int group_by_size(uint32_t n);
+inline ForcePlan plan_force(const PedoniModel* m, uint32_t n, bool whole_array)
+{
+    ForcePlan p{1, m->force_choice.build, m->force_choice.slots};
+    if (p.build == ForceBuild::BySize) {
+        // 6 candidate slots per lane and batch in the 94-SGPR, 7-waves-per-SIMD build from 4e5 agents up
+        // (96.2 us against 100.5 us for the default build at N = 1e6, round 2); smaller crowds, whose
+        // waves are few anyway, run the default build with 8-slot batches -- or the group kernel
+        const ForcePlan by_n = n >= 400000u ? ForcePlan{1, ForceBuild::S94, 6} : ForcePlan{1, ForceBuild::Default, 8};
+        p.build = by_n.build; p.slots = by_n.slots;
+        p.group = m->force_group > 0 ? m->force_group : group_by_size(n);
+        if (!whole_array) p.group = 1;
+        if (p.group > 1) {
+            p.build = ForceBuild::Default;
+            p.slots = m->force_group_slots == 4 || m->force_group_slots == 6 || m->force_group_slots == 8
+                          ? m->force_group_slots : (p.group == 2 ? 8 : 6);   // (C2: 8 slots 49.9 us, 6 slots 50.5)
+        }
+    }
+    return p;
+}
+
 // Lanes per agent of the force kernel by crowd size (kernels.hpp force_kernel_queue_group), from
 // tools/group_n_sweep.sh on MI355X (profiles/r03_group_n_sweep.txt; tick, us, G = 1 / 2 / 4):
 // N = 25 000: 34.2 / 27.1 / 24.7; 50 000: 34.7 / 28.6 / 29.1; 1e5: 34.1 / 32.0 / 34.9; 2e5: 43.6 / 42.8 / 47.9;
@@ -406,7 +431,7 @@ inline uint32_t blocks_for(uint32_t n, uint32_t bs) { return std::max(1u, (n + b
 // Small launches are bound by their heaviest wave's critical path, which the group form shortens;
 // from ~3e5 agents on the SIMDs are busy and the group's redundant per-agent work costs more than
 // the shorter path brings.
-inline int group_by_size(uint32_t n) { return n < 40000u ? 4 : (n < 250000u ? 2 : 1); }
+int group_by_size(uint32_t n) { return n < 40000u ? 4 : (n < 250000u ? 2 : 1); }
 
 // sfm.rs:58-88 on the device
 int sort_despawn(PedoniModel* m)
@@ -619,9 +644,7 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         // force_kernel_queue_s94): 96.2 us against 100.5 us at N = 1e6, exact mode; small crowds
         // (few waves per SIMD anyway) run the default build with 8-slot batches.  PEDONI_FORCE_SLOTS overrides:
         // 4 / 5 (s94), 6, 8, 15 (5 slots, default SGPRs), 16 / 18 (s94 with 6 / 8 slots).
-        ForceChoice c = m->force_choice;
-        if (c.build == ForceBuild::BySize)   // (small crowds: 8-slot batches, 2-3 % over 6: tools/slots_sweep.sh at N = 1e5 .. 2.5e5)
-            c = n >= 400000u ? ForceChoice{ForceBuild::S94, 6} : ForceChoice{ForceBuild::Default, 8};
+        const ForcePlan c = plan_force(m, n, part == 0);
 #ifdef PEDONI_DIAGNOSTICS
         // diagnostic instantiations (per-phase trace, ablation switches): a build of their own
         if (m->d_trace && (size_t)grid.x * FORCE_WAVES <= TRACE_WAVES) {
@@ -680,11 +703,10 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
             else hipLaunchKernelGGL(exact_kernel, grid, block, 0, stream, a);
         };
         // small crowds: G lanes per agent (kernels.hpp force_kernel_queue_group) -- whole-array launches only
-        int group = m->force_group > 0 ? m->force_group : group_by_size(n);
-        if (part != 0 || m->force_choice.build != ForceBuild::BySize) group = 1;
+        const int group = c.group;
         if (group > 1) {
             grid = dim3(blocks_for(n, FORCE_THREADS / (uint32_t)group));
-            const int gs = m->force_group_slots ? m->force_group_slots : (group == 2 ? 8 : 6);   // (C2: 8 slots 49.9 us, 6 slots 50.5)
+            const int gs = c.slots;
             if (group == 2) {
                 if (gs == 8) launch(force_kernel_queue_group<0, 8, 2>, force_kernel_queue_group<1, 8, 2>);
                 else if (gs == 4) launch(force_kernel_queue_group<0, 4, 2>, force_kernel_queue_group<1, 4, 2>);
@@ -1646,6 +1668,34 @@ int pedoni_hip_halo_tick_end(PedoniModel* m)
     HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_interior, 0)); // join before the next pass
     after_update(m);
     m->split_pending = false;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_force_kernel_info(PedoniModel* m, uint32_t n_agents, char* name, uint32_t name_cap,
+                                 uint32_t* agents_per_wave)
+{
+    if (!m) return fail(PEDONI_E_INVALID, "null model");
+    const bool fast = m->opt.math_mode == PEDONI_MATH_FAST;
+    std::string sym;
+    uint32_t per_wave = 64;
+    if (!m->opt.use_neighbor_grid || m->force_simple) {
+        sym = std::string("force_kernel_simple<") + (fast ? "1" : "0") + ">";
+    } else {
+        const ForcePlan c = plan_force(m, n_agents, true);
+        const std::string mode = fast ? "1" : "0";
+        if (c.group > 1) {
+            sym = "force_kernel_queue_group<" + mode + ", " + std::to_string(c.slots) + ", " + std::to_string(c.group) + ">";
+            per_wave = 64u / (uint32_t)c.group;
+        } else {
+            sym = std::string(c.build == ForceBuild::S94 ? "force_kernel_queue_s94<" : "force_kernel_queue<") + mode + ", " +
+                  std::to_string(c.slots) + ">";
+        }
+    }
+    if (name && name_cap) {
+        std::strncpy(name, sym.c_str(), name_cap - 1);
+        name[name_cap - 1] = '\0';
+    }
+    if (agents_per_wave) *agents_per_wave = per_wave;
     return PEDONI_OK;
 }
 

@@ -43,11 +43,14 @@ def test_bench_line_of_a_small_single_gpu_run():
     # the committed 1e6-agent counter profile is not applied to a 2e5-agent launch as is: instruction
     # counts are scaled by waves, traffic is only quoted for the profiled size
     assert r["traffic"] is None
+    # the run at 2e5 agents launches the 2-lanes-per-agent kernel; its instruction floor is only quoted
+    # from a committed counter profile of THAT kernel (None until one exists), scaled by waves
+    assert r["kernel_symbol"].startswith("force_kernel_queue_group<0,")
     v = r["valu"]
-    agents = d["config"]["agents_total"]
-    assert v["waves"] == (agents + 63) // 64 and v["profile_waves"] > 3 * v["waves"]
-    assert math.isclose(v["insts_per_launch"], v["insts_per_wave"] * v["waves"], rel_tol=1e-9)
-    assert 0 < v["frac"] < 1
+    if v is not None:
+        agents = d["config"]["agents_total"]
+        assert v["kernel_symbol"].endswith(r["kernel_symbol"]) and v["waves"] == (agents + 31) // 32
+        assert math.isclose(v["insts_per_launch"], v["insts_per_wave"] * v["waves"], rel_tol=1e-9)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert math.isclose(d["vs_baseline"], d["value"] / c["value"], rel_tol=1e-9)

@@ -361,11 +361,16 @@ def test_bench_picks_the_newest_committed_profile():
         mine = [q for q in sorted(Path(bench.ROOT / "profiles").glob("*pmc_force*.json"), key=bench._by_age)
                 if bench._profile_workload(q.name) == key]
         assert tag == mine[-1].name and traffic["high"] > traffic["low"] > 0
-        floor = bench.valu_floor(0.09, key, 1_000_000 if key != "c2" else 100_000, fast=False)
-        assert floor and bench._profile_workload(floor["profile"]) == key and "<0," in floor["kernel_symbol"]
+    for key in ("c3", "c4", "c4seg"):
+        floor = bench.valu_floor(0.09, key, 1_000_000, "force_kernel_queue_s94<0, 6>")
+        assert floor and bench._profile_workload(floor["profile"]) == key
+        assert floor["kernel_symbol"].endswith("force_kernel_queue_s94<0, 6>")       # never the diagnostics' persistent kernel
     # an 8e6-agent launch is priced with 8x the waves of the 1e6-agent profile, not with its launch total
-    f1, f8 = bench.valu_floor(0.09, "c3", 1_000_000, False), bench.valu_floor(0.72, "c3", 8_000_000, False)
+    f1 = bench.valu_floor(0.09, "c3", 1_000_000, "force_kernel_queue_s94<0, 6>")
+    f8 = bench.valu_floor(0.72, "c3", 8_000_000, "force_kernel_queue_s94<0, 6>")
     assert abs(f8["insts_per_launch"] / f1["insts_per_launch"] - 8.0) < 1e-3 and abs(f8["frac"] / f1["frac"] - 1.0) < 1e-3
+    # a kernel nobody has profiled yields no floor rather than another kernel's
+    assert bench.valu_floor(0.05, "c3", 100_000, "force_kernel_queue_group<0, 9, 2>", 32) is None
 
 
 # ---- the RCCL side of the shard driver, as far as a CPU can see it ---------------------------

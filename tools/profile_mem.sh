@@ -10,9 +10,27 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 B="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-profile --no-fast-leg $*"
+rocprofv3 -L > "$OUT/counters_available.txt" 2>&1 || true
+# A counter set the hardware cannot collect aborts rocprofv3, which then may never exit: every pass is
+# checked BEFORE it is launched -- each counter must be in `rocprofv3 -L`, and a pass may hold at most
+# 2 TA, 2 TD and 4 TCP counters (the per-block limits met on gfx950) -- and is refused otherwise.  The
+# timeout below stays as the backstop, not as the mechanism.
+check_pass() {
+    local name=$1; shift
+    local ta=0 td=0 tcp=0 c
+    for c in "$@"; do
+        if [ -s "$OUT/counters_available.txt" ] && ! grep -qw "$c" "$OUT/counters_available.txt"; then
+            echo "pass $name REFUSED: counter $c is not in rocprofv3 -L"; return 1
+        fi
+        case $c in TA_*) ta=$((ta+1));; TD_*) td=$((td+1));; TCP_*) tcp=$((tcp+1));; esac
+    done
+    if [ $ta -gt 2 ] || [ $td -gt 2 ] || [ $tcp -gt 4 ]; then
+        echo "pass $name REFUSED: $ta TA / $td TD / $tcp TCP counters (limits 2 / 2 / 4 per pass)"; return 1
+    fi
+}
 pass() {
     name=$1; shift
-    # (a counter set the hardware cannot collect aborts rocprofv3, which then may never exit)
+    check_pass "$name" "$@" || return 0
     timeout -k 10 150 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$OUT/$name" -- $B > "$OUT/$name.log" 2>&1 \
         || echo "pass $name failed (kept going)"
     echo "pass $name done"
