@@ -228,7 +228,7 @@ def _by_age(path):
     return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", path.name)]
 
 
-def pmc_traffic(workload_key: str, kernel_symbol_part: str = "force_kernel"):
+def pmc_traffic(workload_key: str, kernel_symbol: str = ""):
     """Fabric-side bytes per force-kernel launch from the newest committed rocprofv3 --pmc passes
     (profiles/*pmc_force*.json, tools/pmc_summary.py) taken on THIS workload -- (dict, tag) or
     (None, None).  `high` = 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction, calibrated
@@ -242,7 +242,9 @@ def pmc_traffic(workload_key: str, kernel_symbol_part: str = "force_kernel"):
             d = json.loads(p.read_text())
         except Exception:
             continue
-        if _profile_workload(p.name) == workload_key and kernel_symbol_part in d.get("kernel_symbol", "force_kernel"):
+        sym = d.get("kernel_symbol", "").split("::")[-1]
+        # (profiles of round 1-2 carry no symbol: they are the one-lane kernel's)
+        if _profile_workload(p.name) == workload_key and (not kernel_symbol or not sym or sym == kernel_symbol):
             fetch, write = (d.get("fetch_size_kb_raw") or 0.0) * 1024.0, (d.get("write_size_kb") or 0.0) * 1024.0
             best = ({"high": 2.0 * fetch + write, "low": fetch + write}, p.name)
     return best
@@ -628,8 +630,8 @@ def main() -> None:
         if fk and fk["launches"]:
             avg_ms = fk["total_ms"] / fk["launches"]
             achieved = BYTES_FORCE * agents_local / (avg_ms * 1e-3) / 1e9
-            traffic, traffic_tag = pmc_traffic(args.workload) if G == 1 and n_per in (100_000, 1_000_000) else (None, None)
             ksym, per_wave = model.force_kernel_info(int(agents_local))
+            traffic, traffic_tag = pmc_traffic(args.workload, ksym) if G == 1 and n_per in (100_000, 1_000_000) else (None, None)
             valu = valu_floor(avg_ms, args.workload, agents_local, ksym, per_wave) if G == 1 else None
             hbm_frac = achieved / HBM_PEAK_GBS
             out["roofline"] = {
