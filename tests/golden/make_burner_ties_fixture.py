@@ -32,9 +32,18 @@ def ties(path):
     for seg in sc.obstacle_array():
         exact |= t._exact_traversal(t._outline_cells(seg), rows, cols)
     rr, cc = np.nonzero(exact != got.obstacle_exist)
+    # the waypoint outlines (field.rs:66-88): the zero set of each potential map
+    wp = []
+    for k, seg in enumerate(sc.waypoint_array()):
+        zero = got.potential_maps[k] == 0
+        ex = t._exact_traversal(t._outline_cells(seg), rows, cols)
+        wr, wc = np.nonzero(ex != zero)
+        wp += [[int(k), int(r), int(c), int(zero[r, c])] for r, c in zip(wr, wc)]
     return {"shape": [rows, cols], "burnt_cells": int(got.obstacle_exist.sum()),
             # [row, col, this build burns it (1) / only the exact traversal does (0)]
-            "cells": [[int(r), int(c), int(got.obstacle_exist[r, c])] for r, c in zip(rr, cc)]}
+            "cells": [[int(r), int(c), int(got.obstacle_exist[r, c])] for r, c in zip(rr, cc)],
+            # [waypoint, row, col, this build burns it (1) / only the exact traversal does (0)]
+            "waypoint_cells": wp}
 
 
 def main():
@@ -45,7 +54,9 @@ def main():
             files.setdefault("reference:" + p.name, p)
     out = {name: ties(p) for name, p in files.items()}
     (ROOT / "tests" / "golden" / "burner_corner_ties.json").write_text(json.dumps(out, indent=1) + "\n")
-    print({k: len(v["cells"]) for k, v in out.items()}, "total", sum(len(v["cells"]) for v in out.values()))
+    print({k: (len(v["cells"]), len(v["waypoint_cells"])) for k, v in out.items()})
+    print("obstacle-mask cells", sum(len(v["cells"]) for v in out.values()), "waypoint-outline cells",
+          sum(len(v["waypoint_cells"]) for v in out.values()))
 
 
 if __name__ == "__main__":
