@@ -13,7 +13,7 @@ import pytest
 
 from helpers import (GOLDEN, bit_equal, box_scenario, inject_crowd, oracle_field,
                      random_obstacle_scenario, rel_close)
-from pedoni_amd import scenario as scn
+from pedoni_amd import abi, scenario as scn
 
 pytestmark = pytest.mark.gpu
 
@@ -867,3 +867,85 @@ def test_create_destroy_does_not_leak_device_memory(hip, oracle):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of device memory not returned"
+
+
+@pytest.mark.parametrize("env", [{"PEDONI_FORCE_GROUP": "1"}, {"PEDONI_FORCE_GROUP": "2"}, {"PEDONI_FORCE_GROUP": "4"},
+                                 {"PEDONI_FORCE_GROUP": "2", "PEDONI_FORCE_GROUP_SLOTS": "4"},
+                                 {"PEDONI_FORCE_GROUP": "4", "PEDONI_FORCE_GROUP_SLOTS": "8"},
+                                 {"PEDONI_FORCE_KERNEL": "s94:6"}, {"PEDONI_FORCE_KERNEL": "s94:4"},
+                                 {"PEDONI_FORCE_KERNEL": "default:8"}, {"PEDONI_FORCE_KERNEL": "default:5"}])
+@pytest.mark.parametrize("use_distance_map", [True, False])
+def test_every_force_kernel_instantiation_reproduces_the_oracle(hip, oracle, monkeypatch, env, use_distance_map):
+    """The by-size rule (pedoni_hip.hip plan_force / group_by_size) picks ONE instantiation of the force
+    kernel per crowd size -- 2 or 4 lanes per agent for small crowds, the one-lane kernel in its
+    default or 94-SGPR build above -- so a crowd of one size would only ever test one of them.
+    Here each is pinned in turn on the same crowd (30 000 agents among 100 walls, 300 of them
+    packed into one cell: a lane with hundreds of candidates beside lanes with a dozen) and must
+    give the oracle's accelerations and 4 ticks of its state, bit for bit, on both wall paths."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc = random_obstacle_scenario(120.0, 100)
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 30_000, 4, seed=77)
+    rng = np.random.default_rng(5)
+    pos[:300] = (np.array([60.3, 61.0]) + rng.uniform(0.0, 1.0, (300, 2))).astype(np.float32)   # one crowded cell
+    obstacles = sc.obstacle_array()
+    cpu = oracle.OracleModel(sc.field.size, use_distance_map=use_distance_map)
+    gpu = hip.HipModel(hip.Options(use_distance_map=use_distance_map), sc.field.size, field.distance_map,
+                       field.potential_maps, field.unit, obstacles)
+    want_symbol = {"1": "force_kernel_queue<0, 8>", "2": "force_kernel_queue_group<0, ", "4": "force_kernel_queue_group<0, "}
+    sym, per_wave = gpu.force_kernel_info(30_000)
+    if "PEDONI_FORCE_GROUP" in env:
+        assert sym.startswith(want_symbol[env["PEDONI_FORCE_GROUP"]]) and per_wave == 64 // int(env["PEDONI_FORCE_GROUP"])
+        if "PEDONI_FORCE_GROUP_SLOTS" in env:
+            assert f", {env['PEDONI_FORCE_GROUP_SLOTS']}, " in sym
+    else:
+        build, slots = env["PEDONI_FORCE_KERNEL"].split(":")
+        assert sym == ("force_kernel_queue_s94" if build == "s94" else "force_kernel_queue") + f"<0, {slots}>"
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    assert bit_equal(gpu.calc_accelerations(cpu.get_pedestrian_count()), cpu.calc_accelerations(field, obstacles)).all()
+    for step in range(4):
+        cpu.update_states(field, obstacles)
+        gpu.update_states()
+        cpu.spawn_pedestrians(field)
+        gpu.spawn_pedestrians()
+        assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices())
+        _assert_state_equal(gpu.download(), cpu.download(), f"{env} step {step}")
+    gpu.tick_n(6)                      # (captured pairs replay the pinned kernel too)
+    for _ in range(6):
+        cpu.spawn_pedestrians(field)
+        cpu.update_states(field, obstacles)
+    gpu.sort_despawn(); cpu.spawn_pedestrians(field)
+    _assert_state_equal(gpu.download(), cpu.download(), f"{env} after tick_n")
+    gpu.close()
+
+
+def test_group_kernel_fast_mode_within_1e5_of_exact(hip, oracle, monkeypatch):
+    """PEDONI_MATH_FAST through the lanes-per-agent kernel: within north_star's 1e-5 of the exact mode
+    per step from identical state, for every agent (same bar as test_fast_math_mode_within_1e5)."""
+    sc = random_obstacle_scenario(120.0, 100)
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = inject_crowd(field, sc.field.size, 40_000, 4, seed=78)
+    worst = 0.0
+    for group in ("2", "4"):
+        monkeypatch.setenv("PEDONI_FORCE_GROUP", group)
+        out = {}
+        for mode in (abi.MATH_EXACT, abi.MATH_FAST):
+            gpu = hip.HipModel(hip.Options(math_mode=mode), sc.field.size, field.distance_map, field.potential_maps,
+                               field.unit, sc.obstacle_array())
+            gpu.append(pos, dest, v0, vel)
+            gpu.sort_despawn()
+            acc = gpu.calc_accelerations(len(pos))
+            gpu.update_states()
+            out[mode] = (acc, gpu.download())
+            gpu.close()
+        acc_e, (pe, _, ve, _) = out[abi.MATH_EXACT]
+        acc_f, (pf, _, vf, _) = out[abi.MATH_FAST]
+        scale = np.maximum(np.linalg.norm(ve, axis=1), np.linalg.norm(acc_e, axis=1) * 0.1) + 1e-30
+        with np.errstate(invalid="ignore"):
+            err = np.linalg.norm(vf.astype(np.float64) - ve, axis=1) / scale
+        err = err[np.isfinite(err)]
+        worst = max(worst, float(err.max()))
+    assert worst <= 1e-5, worst
