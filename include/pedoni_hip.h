@@ -331,6 +331,8 @@ int pedoni_hip_debug_set_ablate(PedoniModel* m, uint32_t bits);
  * prologue, phases 1 / 2 / 3 and the epilogue (sums7[0..4]), their lifetimes ([5]) and their
  * number ([6]); tools/force_trace.py prints the shares */
 int pedoni_hip_debug_force_trace(PedoniModel* m, uint64_t* sums7, int32_t reset);
+/* the raw records behind it: 8 words per wave -- the five phase sums, lifetime, launches, start stamp */
+int pedoni_hip_debug_force_trace_raw(PedoniModel* m, uint64_t* out, uint32_t n_waves);
 #endif /* PEDONI_DIAGNOSTICS */
 
 /* [ext] device self-test hooks used by tests/: evaluate one device math primitive over

@@ -48,7 +48,8 @@ SYMBOLS = [
 
 
 # the diagnostics build (pedoni_amd/lib/libpedoni_hip_diag.so, -DPEDONI_DIAGNOSTICS) adds these
-DIAG_SYMBOLS = ["pedoni_hip_debug_set_status", "pedoni_hip_debug_set_ablate", "pedoni_hip_debug_force_trace"]
+DIAG_SYMBOLS = ["pedoni_hip_debug_set_status", "pedoni_hip_debug_set_ablate", "pedoni_hip_debug_force_trace",
+                "pedoni_hip_debug_force_trace_raw"]
 
 
 class PedoniError(RuntimeError):
@@ -454,6 +455,13 @@ class HipModel:
         out = (C.c_uint64 * 7)()
         _check(self._lib, self._lib.pedoni_hip_debug_force_trace(self._h, out, C.c_int32(int(reset))))
         return [int(x) for x in out]
+
+    def debug_force_trace_raw(self, n_waves: int) -> np.ndarray:
+        """(n_waves, 8) u64: per wave the five phase sums, lifetime, launches, start stamp."""
+        out = np.zeros((n_waves, 8), np.uint64)
+        _check(self._lib, self._lib.pedoni_hip_debug_force_trace_raw(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                                     C.c_uint32(n_waves)))
+        return out
 
     def debug_set_status(self, word: int) -> None:
         """Test hook: overwrite the sticky device status word (0 clears it)."""

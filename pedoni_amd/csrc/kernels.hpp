@@ -1077,10 +1077,33 @@ template <int G> __device__ __forceinline__ float group_lane(float v, int g)
     return __int_as_float(r);
 }
 
-template <int MODE, int SLOTS, int G>
+template <int MODE, int SLOTS, int G, bool TRACE = false>
 __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const uint32_t tile, float2* __restrict__ queue,
                                                        uint32_t* __restrict__ who, const uint64_t* __restrict__ tab)
 {
+    // TRACE (diagnostics build): per wave, the shader cycles spent in prologue / phase 1 / 2 / 3 /
+    // epilogue, its lifetime, 1, and its start stamp: a.trace[8 * tile + 0..7]
+    unsigned long long tr_t0 = 0, tr_mark = 0, tr_acc[5] = {0, 0, 0, 0, 0};
+    auto tr_lap = [&](int which) {
+        if constexpr (TRACE) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tr_acc[which] += now - tr_mark;
+            tr_mark = now;
+        }
+    };
+    auto tr_flush = [&]() {
+        if constexpr (TRACE) {
+            if ((threadIdx.x & 63u) == 0 && a.trace) {
+                tr_lap(4);
+                unsigned long long* rec = a.trace + 8ull * tile;
+                for (int k = 0; k < 5; ++k) rec[k] += tr_acc[k];
+                rec[5] += __builtin_amdgcn_s_memtime() - tr_t0;
+                rec[6] += 1ull;
+                rec[7] = tr_t0;
+            }
+        }
+    };
+    if constexpr (TRACE) tr_t0 = tr_mark = __builtin_amdgcn_s_memtime();
     constexpr uint32_t PER_WAVE = 64u / (uint32_t)G;
     const uint32_t lane = threadIdx.x & 63u, sub = lane & (uint32_t)(G - 1);
     const uint32_t id = a.base + tile * PER_WAVE + lane / (uint32_t)G;
@@ -1142,6 +1165,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
     const uint32_t n01 = n0 + n1, r1s = r1 - n0, r2s = r2 - n01;
     const uint32_t id_safe = valid ? id : a.base;
 
+    tr_lap(0);
     // one batch = SLOTS slots per lane = G * SLOTS consecutive slots of the agent
     for (uint32_t base = 0; base < max_cnt; base += (uint32_t)(G * SLOTS)) {
         // ---- phase 1: this lane's share of the batch: slots base + sub, base + sub + G, ... ----
@@ -1177,6 +1201,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
         queue[(uint32_t)(SLOTS * 64) + lane] = make_float2(-0.0f, -0.0f);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        tr_lap(1);
 
         // ---- phase 2: one pair force per lane (as in the one-lane kernel) ---------------------
         for (uint32_t q0 = 0; q0 < qlen; q0 += 64) {
@@ -1194,6 +1219,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        tr_lap(2);
 
         // ---- phase 3: the group's ordered sum, formed alike on each of its lanes (sfm.rs:153) ----
         float2 fr[SLOTS];
@@ -1207,11 +1233,13 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        tr_lap(3);
     }
 
     if (!valid) {
         // slot of a despawned agent (whole-array launches only)
         if (writer && a.key_next && id < a.key_end) a.key_next[id] = DEAD;
+        tr_flush();
         return;
     }
     if (ghost) {                                                  // ghost row: never integrated
@@ -1221,6 +1249,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
             a.velx_out[id] = vv;
             if (a.key_next) a.key_next[id] = DEAD;
         }
+        tr_flush();
         return;
     }
     uint32_t dest_k = 0;
@@ -1232,7 +1261,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
     if (a.use_distance_map) acc = acc + wall;                     // (= obstacle_force_map: direction * k, lane 1's)
     else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
 
-    if (a.acc_out) { if (writer) a.acc_out[id] = make_float2(acc.x, acc.y); return; }
+    if (a.acc_out) { if (writer) a.acc_out[id] = make_float2(acc.x, acc.y); tr_flush(); return; }
 
     // integrator, sfm.rs:245-254
     v2 vel_prev = vel;
@@ -1260,6 +1289,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
         if (writer) a.key_next[id] = k;
         count_key(a.cell_count, a.row_count, writer && k != DEAD, k, (uint32_t)cy);
     }
+    tr_flush();
 }
 
 template <int MODE, int SLOTS, int G>
@@ -1270,6 +1300,17 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_group(ForceA
     const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
     force_queue_tile_group<MODE, SLOTS, G>(a, block * FORCE_WAVES + wave, queue_all[wave], who_all[wave], tab);
 }
+
+#ifdef PEDONI_DIAGNOSTICS
+template <int MODE, int SLOTS, int G>
+__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_group_trace(ForceArgs a)
+{
+    PEDONI_FORCE_LDS(SLOTS);
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    force_queue_tile_group<MODE, SLOTS, G, true>(a, block * FORCE_WAVES + wave, queue_all[wave], who_all[wave], tab);
+}
+#endif
 
 #ifdef PEDONI_DIAGNOSTICS
 // diagnostic build of the 7-wave kernel with the extended ablation switches (PEDONI_ABLATE bits 8

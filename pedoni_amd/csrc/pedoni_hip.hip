@@ -647,6 +647,15 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         const ForcePlan c = plan_force(m, n, part == 0);
 #ifdef PEDONI_DIAGNOSTICS
         // diagnostic instantiations (per-phase trace, ablation switches): a build of their own
+        if (m->d_trace && c.group > 1) {       // per-wave records of the group kernel (tools/group_trace.py)
+            const dim3 ggrid(blocks_for(n, FORCE_THREADS / (uint32_t)c.group));
+            if ((size_t)ggrid.x * FORCE_WAVES <= TRACE_WAVES) {
+                if (c.group == 2) hipLaunchKernelGGL((force_kernel_queue_group_trace<0, 8, 2>), ggrid, block, 0, stream, a);
+                else hipLaunchKernelGGL((force_kernel_queue_group_trace<0, 6, 4>), ggrid, block, 0, stream, a);
+                HIP_TRY(hipGetLastError());
+                return PEDONI_OK;
+            }
+        }
         if (m->d_trace && (size_t)grid.x * FORCE_WAVES <= TRACE_WAVES) {
             if (fast) hipLaunchKernelGGL((force_kernel_queue_trace<1, 6>), grid, block, 0, stream, a);
             else hipLaunchKernelGGL((force_kernel_queue_trace<0, 6>), grid, block, 0, stream, a);
@@ -1748,6 +1757,16 @@ int pedoni_hip_debug_set_status(PedoniModel* m, uint32_t status_word)
     TRY(bind(m));
     HIP_TRY(hipMemcpyAsync(m->d_live + 1, &status_word, sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    return PEDONI_OK;
+}
+
+// diagnostics: the raw per-wave trace records (8 words each; see force_queue_tile_group TRACE)
+int pedoni_hip_debug_force_trace_raw(PedoniModel* m, uint64_t* out, uint32_t n_waves)
+{
+    TRY(bind(m));
+    if (!m->d_trace || !out || n_waves > TRACE_WAVES) return fail(PEDONI_E_INVALID, "force trace raw: bad arguments");
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(out, m->d_trace, (size_t)n_waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PEDONI_OK;
 }
 
