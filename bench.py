@@ -489,10 +489,13 @@ def main() -> None:
                     model.append(pos, dest, v0, vel)
                     shard.begin()
                     shard.tick_n(4); shard.set_overlap(True); shard.tick_n(4); shard.set_overlap(False)
+                    # two communicators on one device (the library's and torch's): never both in flight --
+                    # every rank drains the first before any rank starts on the second
+                    torch.cuda.synchronize(); dist.barrier()
                     ref_model = new_model()
                     ref = torch_runner(ref_model)
                     ref.tick_n(8)
-                    torch.cuda.synchronize()
+                    torch.cuda.synchronize(); dist.barrier()
                     a, b = model.download(), ref_model.download()
                     same = all(x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32))
                                for x, y in zip(a, b))
