@@ -485,25 +485,41 @@ def main() -> None:
                 # (4 plain + 4 overlapped) against 8 ticks of the torch all_gather driver on a second
                 # model with the same crowd; every rank compares the two states bit for bit.
                 stage("verify direct exchange against all_gather", 240.0)
+                # (staged: after each stage every rank learns whether ALL ranks got through it -- a rank
+                # that failed never leaves the others inside a collective it will not join; the
+                # all-reduce of `agreed` is also the barrier that keeps the two communicators, the
+                # library's and torch's, from ever being in flight on one device together)
+                ref_model = None
                 try:
                     model.append(pos, dest, v0, vel)
                     shard.begin()
                     shard.tick_n(4); shard.set_overlap(True); shard.tick_n(4); shard.set_overlap(False)
-                    # two communicators on one device (the library's and torch's): never both in flight --
-                    # every rank drains the first before any rank starts on the second
-                    torch.cuda.synchronize(); dist.barrier()
-                    ref_model = new_model()
-                    ref = torch_runner(ref_model)
-                    ref.tick_n(8)
-                    torch.cuda.synchronize(); dist.barrier()
-                    a, b = model.download(), ref_model.download()
-                    same = all(x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32))
-                               for x, y in zip(a, b))
-                    ref_model.close()
-                    if not same:
-                        ok, why = 0, "direct-exchange state differs from the all_gather driver's after 8 ticks"
+                    torch.cuda.synchronize()
                 except Exception as e:             # noqa: BLE001
                     ok, why = 0, str(e)
+                if agreed(ok):
+                    try:
+                        ref_model = new_model()
+                    except Exception as e:         # noqa: BLE001
+                        ok, why = 0, str(e)
+                    if agreed(ok):
+                        try:
+                            ref = torch_runner(ref_model)
+                            ref.tick_n(8)
+                            torch.cuda.synchronize()
+                            a, b = model.download(), ref_model.download()
+                            same = all(x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32))
+                                       for x, y in zip(a, b))
+                            if not same:
+                                ok, why = 0, "direct-exchange state differs from the all_gather driver's after 8 ticks"
+                        except Exception as e:     # noqa: BLE001
+                            ok, why = 0, str(e)
+                    else:
+                        ok = 0
+                else:
+                    ok = 0
+                if ref_model is not None:
+                    ref_model.close()
                 ok = 1 if agreed(ok) else 0
                 verified = bool(ok)
             if ok == 1:
