@@ -1313,6 +1313,24 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_group_trace(
 #endif
 
 #ifdef PEDONI_DIAGNOSTICS
+// experiment: ONE wave per workgroup (the dispatcher refills at wave granularity, no block barrier)
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(64, 7) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_w1(ForceArgs a)
+{
+    __shared__ uint64_t tab[32];
+    __shared__ float2 queue1[SLOTS * 64 + 64];
+    __shared__ uint32_t who1[SLOTS * 64 + 64];
+    if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // XCD-contiguous order at the granularity of 4 tiles, as the 4-wave kernel's
+    const uint32_t quad = a.xcd_remap ? xcd_contiguous_block(blockIdx.x >> 2, (gridDim.x + 3u) >> 2) : (blockIdx.x >> 2);
+    force_queue_tile<MODE, SLOTS>(a, (quad * 4u + (blockIdx.x & 3u)) * 64u + threadIdx.x, queue1, who1, tab);
+}
+#endif
+
+#ifdef PEDONI_DIAGNOSTICS
 // diagnostic build of the 7-wave kernel with the extended ablation switches (PEDONI_ABLATE bits 8
 // and up; tools/ablate_launch.py): a build of its own, so that the product kernels carry none of it
 template <int MODE, int SLOTS>

@@ -670,6 +670,13 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         }
 #endif
 #ifdef PEDONI_DIAGNOSTICS
+        if (m->force_persist == 21 && part == 0) {     // experiment: one wave per workgroup
+            const dim3 g1(((blocks_for(n, 64) + 3u) / 4u) * 4u), b1(64);
+            if (fast) hipLaunchKernelGGL((force_kernel_queue_w1<1, 6>), g1, b1, 0, stream, a);
+            else hipLaunchKernelGGL((force_kernel_queue_w1<0, 6>), g1, b1, 0, stream, a);
+            HIP_TRY(hipGetLastError());
+            return PEDONI_OK;
+        }
         // persistent-wave forms (kernels.hpp: a measured dead end, PEDONI_FORCE_PERSIST): whole-array
         // launches right after a sort pass, whose place kernel zeroed the tile tickets
         const bool persist = part == 0 && !on && m->tickets_fresh && c.build == ForceBuild::S94 && c.slots == 6 &&
