@@ -1551,7 +1551,11 @@ struct HaloList {            // device layout of one direction's buffer
     // followed by count records of PEDONI_HALO_RECORD_WORDS words
 };
 
-__global__ void __launch_bounds__(1024)
+// (256 threads: in the overlapped sharded tick this kernel is launched while the interior rows' force
+// kernel holds the chip, and a 1024-thread workgroup needs 16 free wave slots on ONE CU before it can
+// start -- it waited 50 us for them and the exchange it feeds started that much later.  A 256-thread
+// workgroup fits wherever one force workgroup retires.)
+__global__ void __launch_bounds__(256)
 halo_pack_kernel(const float2* __restrict__ pos, const float4* __restrict__ velx,
                  const uint32_t* __restrict__ dest, const uint32_t* __restrict__ cs, GridView grid, int32_t band_lo, int32_t band_hi,
                  uint32_t cap_each, uint32_t* __restrict__ send)

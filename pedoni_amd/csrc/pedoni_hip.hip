@@ -994,7 +994,14 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
 
     C_HIP(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
     m->stream = m->own_stream;
-    C_HIP(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+    {
+        // the interior rows of a split sharded tick run on a stream of the LOWEST priority: the edge rows'
+        // small force launch, the pack and the exchange behind it -- the tick's critical path -- must get
+        // the wave slots the interior's thousands of workgroups free, not queue behind them
+        int least = 0, greatest = 0;
+        C_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        C_HIP(hipStreamCreateWithPriority(&m->side_stream, hipStreamNonBlocking, least));
+    }
     C_HIP(hipEventCreateWithFlags(&m->ev_sorted, hipEventDisableTiming));
     C_HIP(hipEventCreateWithFlags(&m->ev_interior, hipEventDisableTiming));
 
@@ -1567,12 +1574,12 @@ int pedoni_hip_halo_bytes(uint32_t cap_each, uint64_t* bytes)
 namespace {
 // `updated` = read positions / velocities from the buffer update_states is writing (the
 // boundary rows of a split tick are already there; the buffers flip when the tick ends)
-int halo_pack_from(PedoniModel* m, void* send_dev, uint32_t cap_each, bool updated)
+int halo_pack_from(PedoniModel* m, void* send_dev, uint32_t cap_each, bool updated, hipStream_t on = nullptr)
 {
     const int src = updated ? 1 - m->pv : m->pv;
-    Timed t(m, PEDONI_K_HALO_PACK);
+    Timed t(m, on ? -1 : PEDONI_K_HALO_PACK);     // (a launch on another stream is not event-timed)
     if (t.rc) return t.rc;
-    hipLaunchKernelGGL(halo_pack_kernel, dim3(2), dim3(1024), 0, m->stream, m->d_pos[src],
+    hipLaunchKernelGGL(halo_pack_kernel, dim3(2), dim3(256), 0, on ? on : m->stream, m->d_pos[src],
                        m->d_velx[src], m->d_dest[m->vd], m->d_cs[m->cs], m->grid,
                        m->band_lo, m->band_hi, cap_each, (uint32_t*)send_dev);
     HIP_TRY(hipGetLastError());

@@ -394,6 +394,45 @@ int shard_start_next(PedoniShard* s)
     return PEDONI_OK;
 }
 
+// Overlapped tick (round 3 form).  Everything that computes stays on the model's stream, in this order:
+// the few rows beside the band's edges FIRST (a small launch), then the interior rows (the bulk).  The
+// pack of the freshly updated edge rows and the exchange of the NEXT tick's lists leave on the shard's
+// own high-priority stream as soon as the edge rows are done, and have the whole interior launch
+// (~85 us) to complete in; the next tick joins on one event that has long fired:
+//     model stream:  unpack, sort/despawn, force(edge rows) [fork] force(interior rows) ......  [join]
+//     comm stream :                                  [wait fork] pack, ncclSend/Recv, [record]
+// What it costs over the plain tick is the edge launch's latency (~15 us: 8 000 agents are 33
+// workgroups, a launch bound by one wave's critical path) -- paid to take the exchange's latency,
+// whatever it is on the node, off the tick.  Forms measured and dropped on the way (kernel
+// timelines, profiles/r03_shard_timeline.txt; one GPU, nothing on the wire, plain tick 124-125 us):
+// round 2's (edge rows + pack on the model's stream, interior on a side stream, exchange on a third:
+// three cross-stream hops of 7-20 us each on the critical path, and a 1024-thread pack workgroup that
+// waited 50 us for 16 free wave slots on one CU) 152 us; edge rows + pack + exchange on a
+// high-priority stream BESIDE the interior launch: 137 us, but the interior's workgroups took the chip
+// first and the edge launch, 33 workgroups, trickled in over 73 us -- the pack ended WITH the
+// interior, the exchange hidden under nothing.
+int shard_tick_split(PedoniShard* s)
+{
+    PedoniModel* m = s->m;
+    TRY(pedoni_hip_halo_unpack(m, shard_below(s), shard_above(s), s->cap));
+    TRY(sort_despawn(m));
+    if (m->band_hi - m->band_lo < 6 || m->force_simple) {        // band too thin to split: the plain sequence
+        TRY(update_states(m));
+        TRY(shard_pack(s));
+        return shard_start_next(s);
+    }
+    TRY(launch_force(m, nullptr, /*part=*/1));                    // edge rows (ghost rows are only NaN-marked)
+    HIP_TRY(hipEventRecord(s->ev_packed, m->stream));             // fork: the edge rows are updated
+    HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_packed, 0));
+    TRY(halo_pack_from(m, s->d_send, s->cap, /*updated=*/true, s->comm_stream));
+    TRY(shard_exchange_rccl(s, s->comm_stream));
+    HIP_TRY(hipEventRecord(s->ev_recv, s->comm_stream));
+    s->in_flight = true;                                          // the next tick joins on ev_recv
+    TRY(launch_force(m, nullptr, /*part=*/2));                    // interior rows
+    after_update(m);
+    return PEDONI_OK;
+}
+
 int shard_tick_rccl(PedoniShard* s)
 {
     PedoniModel* m = s->m;
@@ -401,10 +440,7 @@ int shard_tick_rccl(PedoniShard* s)
     TRY(shard_get_lists(s));
     if (!recut_due(s)) {
         if (s->overlap) {
-            // rows beside the band's edges first, pack, send; the interior rows meanwhile
-            TRY(pedoni_hip_halo_tick_begin(m, shard_below(s), shard_above(s), s->d_send, s->cap));
-            TRY(shard_start_next(s));
-            TRY(pedoni_hip_halo_tick_end(m));
+            TRY(shard_tick_split(s));
         } else {
             TRY(pedoni_hip_halo_tick(m, shard_below(s), shard_above(s), s->d_send, s->cap));
         }
@@ -677,7 +713,10 @@ int pedoni_shard_set_overlap(PedoniShard* s, int32_t on)
         s->lists_ready = true;
     }
     if (on && !s->comm_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+        // (highest priority: its small launches take the wave slots the interior kernel frees)
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&s->comm_stream, hipStreamNonBlocking, greatest));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_packed, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
     }
