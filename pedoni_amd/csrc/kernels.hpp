@@ -1106,10 +1106,26 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
     if constexpr (TRACE) tr_t0 = tr_mark = __builtin_amdgcn_s_memtime();
     constexpr uint32_t PER_WAVE = 64u / (uint32_t)G;
     const uint32_t lane = threadIdx.x & 63u, sub = lane & (uint32_t)(G - 1);
-    const uint32_t id = a.base + tile * PER_WAVE + lane / (uint32_t)G;
-    const uint32_t n = *a.live_count;
-    const bool valid = id < n;
     const bool writer = sub == 0;                 // the group's lane that stores and counts
+    uint32_t id = a.base + tile * PER_WAVE + lane / (uint32_t)G;
+    uint32_t n = *a.live_count;
+    if (a.seg_row[0][0] >= 0) {                   // row-segment launch (the edge rows of a sharded tick)
+        const uint32_t t = tile * PER_WAVE + lane / (uint32_t)G;      // agent slot of this launch
+        const uint32_t b0 = a.cell_start[(int64_t)a.seg_row[0][0] * a.grid.cols];
+        const uint32_t e0 = a.cell_start[(int64_t)a.seg_row[0][1] * a.grid.cols];
+        const uint32_t b1 = a.cell_start[(int64_t)a.seg_row[1][0] * a.grid.cols];
+        const uint32_t e1 = a.cell_start[(int64_t)a.seg_row[1][1] * a.grid.cols];
+        if (t < e0 - b0) { id = b0 + t; n = e0; }
+        else { id = b1 + (t - (e0 - b0)); n = e1; }
+        const uint32_t need = (e0 - b0) + (e1 - b1);
+        if (t == 0 && writer && need > gridDim.x * (blockDim.x / (uint32_t)G)) atomicOr(a.error_word, 4u);
+        if (t >= need) {
+            const uint32_t stale = *a.live_count + (t - need);
+            if (writer && a.clear_stale && a.key_next && stale < a.key_end) a.key_next[stale] = DEAD;
+            id = 0xffffffffu; n = 0;
+        }
+    }
+    const bool valid = id < n;
 
     v2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), acc = mk(0.0f, 0.0f), e = mk(0.0f, 0.0f), wall = mk(0.0f, 0.0f);
     float4 vv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1237,8 +1253,8 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
     }
 
     if (!valid) {
-        // slot of a despawned agent (whole-array launches only)
-        if (writer && a.key_next && id < a.key_end) a.key_next[id] = DEAD;
+        // slot of a despawned agent (whole-array launches only: segments end at live agents)
+        if (writer && a.key_next && a.seg_row[0][0] < 0 && id < a.key_end) a.key_next[id] = DEAD;
         tr_flush();
         return;
     }

@@ -404,6 +404,8 @@ inline uint32_t blocks_for(uint32_t n, uint32_t bs) { return std::max(1u, (n + b
 // pedoni_hip_force_kernel_info reports it (bench.py prices a run with the profile of THAT kernel).
 struct ForcePlan { int group; ForceBuild build; int slots; };
 int group_by_size(uint32_t n);
+// whole_array false = the interior rows of a split sharded tick (one-lane kernel); the EDGE rows' launch
+// (a few thousand agents: bound by one wave's critical path) is planned like a small crowd of its size
 inline ForcePlan plan_force(const PedoniModel* m, uint32_t n, bool whole_array)
 {
     ForcePlan p{1, m->force_choice.build, m->force_choice.slots};
@@ -644,7 +646,7 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         // force_kernel_queue_s94): 96.2 us against 100.5 us at N = 1e6, exact mode; small crowds
         // (few waves per SIMD anyway) run the default build with 8-slot batches.  PEDONI_FORCE_SLOTS overrides:
         // 4 / 5 (s94), 6, 8, 15 (5 slots, default SGPRs), 16 / 18 (s94 with 6 / 8 slots).
-        const ForcePlan c = plan_force(m, n, part == 0);
+        const ForcePlan c = plan_force(m, n, part != 2);
 #ifdef PEDONI_DIAGNOSTICS
         // diagnostic instantiations (per-phase trace, ablation switches): a build of their own
         if (m->d_trace && c.group > 1) {       // per-wave records of the group kernel (tools/group_trace.py)

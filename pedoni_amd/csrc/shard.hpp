@@ -401,9 +401,11 @@ int shard_start_next(PedoniShard* s)
 // (~85 us) to complete in; the next tick joins on one event that has long fired:
 //     model stream:  unpack, sort/despawn, force(edge rows) [fork] force(interior rows) ......  [join]
 //     comm stream :                                  [wait fork] pack, ncclSend/Recv, [record]
-// What it costs over the plain tick is the edge launch's latency (~15 us: 8 000 agents are 33
-// workgroups, a launch bound by one wave's critical path) -- paid to take the exchange's latency,
-// whatever it is on the node, off the tick.  Forms measured and dropped on the way (kernel
+// What it costs over the plain tick is the edge launch (8 000 agents: 9 us on the 4-lanes-per-agent
+// kernel, 15 us on the one-lane kernel) and ~7 us of event record between the two force launches:
+// 140 us per tick against 122 plain on one GPU (bench.py's probe) -- paid to take the exchange's
+// latency, whatever it is on the node, off the tick; bench.py times both forms on the node and keeps
+// the faster.  Forms measured and dropped on the way (kernel
 // timelines, profiles/r03_shard_timeline.txt; one GPU, nothing on the wire, plain tick 124-125 us):
 // round 2's (edge rows + pack on the model's stream, interior on a side stream, exchange on a third:
 // three cross-stream hops of 7-20 us each on the critical path, and a 1024-thread pack workgroup that
@@ -423,12 +425,14 @@ int shard_tick_split(PedoniShard* s)
     }
     TRY(launch_force(m, nullptr, /*part=*/1));                    // edge rows (ghost rows are only NaN-marked)
     HIP_TRY(hipEventRecord(s->ev_packed, m->stream));             // fork: the edge rows are updated
+    // (the interior launch is SUBMITTED before the comm stream's work: the RCCL calls cost the host
+    // ~10 us, which the device would otherwise spend idle between the two force launches)
+    TRY(launch_force(m, nullptr, /*part=*/2));                    // interior rows
     HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_packed, 0));
     TRY(halo_pack_from(m, s->d_send, s->cap, /*updated=*/true, s->comm_stream));
     TRY(shard_exchange_rccl(s, s->comm_stream));
     HIP_TRY(hipEventRecord(s->ev_recv, s->comm_stream));
     s->in_flight = true;                                          // the next tick joins on ev_recv
-    TRY(launch_force(m, nullptr, /*part=*/2));                    // interior rows
     after_update(m);
     return PEDONI_OK;
 }
