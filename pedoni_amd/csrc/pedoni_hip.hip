@@ -1600,6 +1600,15 @@ int pedoni_hip_halo_pack(PedoniModel* m, void* send_dev, uint32_t cap_each)
     return halo_pack_from(m, send_dev, cap_each, /*updated=*/false);
 }
 
+namespace {
+// how many sharded ticks may pass before the host re-reads the device's live count (one stream sync)
+uint32_t tighten_every()
+{
+    static const uint32_t v = [] { const char* e = std::getenv("PEDONI_TIGHTEN_EVERY"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 8u; }();
+    return v;
+}
+} // namespace
+
 int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const void* from_above_dev,
                            uint32_t cap_each)
 {
@@ -1619,7 +1628,7 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
     // 8 ticks -- one stream sync per 8 ticks -- so launches never cover more than ~7 % idle
     // threads; and always before the arrays would have to grow.
     const uint32_t grow = cap_each * std::max(1u, (from_below_dev ? 1u : 0u) + (from_above_dev ? 1u : 0u));
-    if (++m->ticks_since_tighten >= 8 || (uint64_t)m->n_upper + grow > m->cap) {
+    if (++m->ticks_since_tighten >= tighten_every() || (uint64_t)m->n_upper + grow > m->cap) {
         uint32_t live = 0;
         TRY(sync_live_count(m, &live));
         m->ticks_since_tighten = 0;
