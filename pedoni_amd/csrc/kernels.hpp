@@ -417,6 +417,15 @@ __device__ __forceinline__ void reorder_body(const uint32_t* __restrict__ key, u
 //    rows start beyond j and are skipped, so on average half of the 3 x 3 block is read.
 //  general form: a provisional slot by a second round of atomics on the (zeroed) counter;
 //    K_REORDER puts the cell in order and zeroes the counter again.
+#ifdef PEDONI_DIAGNOSTICS
+// diagnostics: parts of place_kernel switched off for ONE timed launch (tools/ablate_place.py; the
+// pass's results are wrong): 1 = no rank scan, 2 = no record move, 4 = no old-range loads
+__device__ int g_place_ablate = 0;
+#define PLACE_ABLATE(bit) (g_place_ablate & (bit))
+#else
+#define PLACE_ABLATE(bit) 0
+#endif
+
 __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
                              GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
                              const uint32_t* __restrict__ cs_new, SortFlags* __restrict__ flags,
@@ -454,22 +463,32 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
     if (!general_cell(flags, parity, band, (int32_t)cy)) {
         // the agent's own record and its cell's start depend on j and c alone: requested BEFORE the
         // rank scan, they arrive while it runs (a latency-bound kernel: one dependent stretch less
-        // per wave, 21 -> 19 us)
+        // per wave, 21 -> 19 us).  (Requested even earlier, together with the key: no further gain,
+        // 18.9-19.5 us; the first 8 keys of each old range fetched at once instead of one dependent
+        // load per candidate: 17.9-18.0 against 18.6-18.8, the tick unchanged -- round 3, not kept.
+        // tools/ablate_place.py: switching off the rank scan, the old-range loads or the 56-byte record
+        // move changes the launch by < 1 us each; tools/microbench/move_records.hip: the bare move of the
+        // same records takes 10 us.)
         const float2 p_in = a.pos_in[j];
         float4 v_in = a.velx_in[j];
         const uint32_t d_in = a.dest_in[j];
         const uint32_t start = cs_new[c];
-        CellRanges r = old_ranges(cs_old, grid, (int32_t)cx, (int32_t)cy);
+        CellRanges r{};
+        if (!PLACE_ABLATE(4)) r = old_ranges(cs_old, grid, (int32_t)cx, (int32_t)cy);
         uint32_t before = 0;
+        if (!PLACE_ABLATE(1)) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const uint32_t hi = min(r.hi[k], j);
-            for (uint32_t i = r.lo[k]; i < hi; ++i) before += key[i] == c ? 1u : 0u;
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t hi = min(r.hi[k], j);
+                for (uint32_t i = r.lo[k]; i < hi; ++i) before += key[i] == c ? 1u : 0u;
+            }
         }
-        const uint32_t to = start + before;
+        const uint32_t to = PLACE_ABLATE(1) ? j : start + before;
         // (`to >= n_total` is never taken unless the live count exceeds the host's bound:
         // scan_rows_kernel has raised STATUS_LIVE_OVERFLOW then; do not write past the arrays)
-        if (to < n_total) {                                      // = move_agent(a, j, to, ..)
+        if (PLACE_ABLATE(2)) {
+            if (to < n_total) a.skey_out[to] = pack_cell(cx, cy) + (uint32_t)(p_in.x + v_in.x) + d_in;
+        } else if (to < n_total) {                               // = move_agent(a, j, to, ..)
             a.pos_out[to] = p_in;
             v_in.z = a.fast ? neighbour_vl<1>(mk(v_in.x, v_in.y)) : neighbour_vl<0>(mk(v_in.x, v_in.y));
             a.velx_out[to] = v_in;

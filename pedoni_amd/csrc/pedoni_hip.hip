@@ -1800,7 +1800,9 @@ int pedoni_hip_debug_force_trace_raw(PedoniModel* m, uint64_t* out, uint32_t n_w
 int pedoni_hip_debug_set_ablate(PedoniModel* m, uint32_t bits)
 {
     TRY(bind(m));
-    m->ablate = (int)bits;
+    m->ablate = (int)(bits & 0xffu);
+    const int place_bits = (int)(bits >> 8);              // bits 8-10: place_kernel's switches (kernels.hpp g_place_ablate)
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pedoni::g_place_ablate), &place_bits, sizeof place_bits));
     m->graph_valid = false;
     return PEDONI_OK;
 }
