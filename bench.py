@@ -557,7 +557,7 @@ def main() -> None:
         for mode in (False, True):
             shard.set_overlap(mode)
             shard.tick_n(5)
-            dist.barrier(); torch.cuda.synchronize()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()   # (the library's exchanges drained before torch's collective starts)
             t0 = time.perf_counter()
             shard.tick_n(20)
             torch.cuda.synchronize()
@@ -576,6 +576,9 @@ def main() -> None:
         step_fn = model.tick_n
 
     def barrier():
+        # (drain first: in the overlapped form an exchange of the library's own communicator may still be
+        # in flight, and two communicators are never given work on one device at the same time)
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
