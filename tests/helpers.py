@@ -63,7 +63,11 @@ def inject_crowd(field, size, n: int, n_dest: int, seed: int = 12345, clearance:
     pos = np.zeros((0, 2), np.float32)
     dest = np.zeros(0, np.uint32)
     unit = field.unit
+    tries = 0
     while len(pos) < n:
+        tries += 1
+        if tries > 200:            # (a field with no cell that qualifies must fail, not spin)
+            raise RuntimeError(f"inject_crowd: only {len(pos)} of {n} positions found in 200 rounds: no free space?")
         m = int((n - len(pos)) * 1.5) + 64
         p = rng.uniform([0.6, 0.6], [size[0] - 0.6, size[1] - 0.6], (m, 2)).astype(np.float32)
         d = rng.integers(0, n_dest, m).astype(np.uint32)

@@ -949,3 +949,56 @@ def test_group_kernel_fast_mode_within_1e5_of_exact(hip, oracle, monkeypatch):
         err = err[np.isfinite(err)]
         worst = max(worst, float(err.max()))
     assert worst <= 1e-5, worst
+
+
+def _rect_scenario(width, height, margin=None):
+    margin = margin if margin is not None else min(width, height) * 0.15
+    sc = scn.Scenario()
+    sc.field = scn.FieldConfig((width, height))
+    sc.waypoints = [scn.SegmentConfig(((margin, margin), (margin, height - margin))),
+                    scn.SegmentConfig(((width - margin, margin), (width - margin, height - margin)))]
+    sc.obstacles = [scn.SegmentConfig(((0, 0), (0, height)), 0.2), scn.SegmentConfig(((width, 0), (width, height)), 0.2),
+                    scn.SegmentConfig(((0, 0), (width, 0)), 0.2), scn.SegmentConfig(((0, height), (width, height)), 0.2),
+                    scn.SegmentConfig(((width * 0.5, height * 0.2), (width * 0.5, height * 0.6)), 0.4)]
+    return sc
+
+
+@pytest.mark.parametrize("width,height,n,grid_unit", [
+    (300.0, 12.0, 6000, 1.4),      # a corridor: 9 grid rows, 215 columns
+    (12.0, 300.0, 6000, 1.4),      # the same on end: 215 rows of 9 cells (rows != cols both ways)
+    (3.0, 3.0, 12, 1.4),           # 3 x 3 cells: every cell touches the border
+    (40.0, 40.0, 3000, 7.0),       # cells far larger than the 2 m cutoff: 6 x 6 cells, ~80 agents each
+    (40.0, 40.0, 3000, 0.5),       # cells smaller than the cutoff: neighbours beyond the 3 x 3 block are missed, as upstream
+    (1.3, 25.0, 40, 1.4),          # ONE column of cells
+])
+@pytest.mark.parametrize("group", ["1", "2", "4"])
+def test_odd_grid_shapes_on_every_lane_layout(hip, oracle, monkeypatch, width, height, n, grid_unit, group):
+    """Grid shapes the bench never has -- a single row band, a single column, cells above and below
+    the cutoff, a field smaller than a wave -- through the one-lane kernel and both lanes-per-agent
+    layouts: cell_start, order and state equal to the oracle's, bit for bit, for 5 ticks."""
+    monkeypatch.setenv("PEDONI_FORCE_GROUP", group)
+    sc = _rect_scenario(width, height)
+    field = oracle_field(oracle, sc)
+    if width < 2.0:          # one column of cells: too narrow for inject_crowd's clearance -- a file of agents down the middle
+        rng = np.random.default_rng(9)
+        pos = np.stack([np.full(n, 0.65) + rng.uniform(-0.05, 0.05, n), np.linspace(3.0, height - 3.0, n)], 1).astype(np.float32)
+        dest = (np.arange(n) % 2).astype(np.uint32)
+        v0 = np.clip(rng.normal(1.34, 0.26, n), 0.5, 2.2).astype(np.float32)
+        vel = np.stack([np.zeros(n), np.where(dest == 1, 0.6, -0.6)], 1).astype(np.float32)
+    else:
+        pos, dest, v0, vel = inject_crowd(field, sc.field.size, n, 2, seed=int(width * 7 + height), clearance=0.3,
+                                          min_potential=0.3)
+    cpu = oracle.OracleModel(sc.field.size, neighbor_grid_unit=grid_unit)
+    gpu = _make_hip(hip, sc, field, neighbor_grid_unit=grid_unit)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.sort_despawn()
+    assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices())
+    for step in range(5):
+        cpu.update_states(field)
+        gpu.update_states()
+        cpu.spawn_pedestrians(field)
+        gpu.spawn_pedestrians()
+        assert np.array_equal(gpu.neighbor_grid_indices(), cpu.neighbor_grid_indices()), step
+        _assert_state_equal(gpu.download(), cpu.download(), f"{width}x{height} unit {grid_unit} group {group} step {step}")
+    gpu.close()
