@@ -201,6 +201,7 @@ struct PedoniModel {
     bool halo_keys_done = false; // halo_unpack_kernel keyed the exchanged agents of this pass
     bool force_simple = false; // PEDONI_FORCE_SIMPLE=1: one-lane-per-agent force kernel
     int ablate = 0;            // PEDONI_ABLATE bitmask: timing diagnostics only, results wrong
+    uint32_t place_ablate = 0; // diagnostics build: place_kernel's switches (pedoni_hip_debug_set_ablate bits 8 and up)
     bool sort_general = false; // PEDONI_SORT_GENERAL=1: always take the atomic (general) sort form
     bool no_fuse_key = false;  // PEDONI_NO_FUSE_KEY=1: standalone K_KEY every tick
     bool xcd_remap = true;     // PEDONI_NO_XCD_REMAP=1: hardware block order
@@ -519,13 +520,45 @@ int sort_despawn(PedoniModel* m)
         {
             Timed t(m, PEDONI_K_SLOT);
             if (t.rc) return t.rc;
+            // (workgroups of 64 ... 1024 threads: the launch takes the same 17.6-18.9 us, tools/place_probe.sh)
             hipLaunchKernelGGL(place_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
                                m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
                                (m->halo_cap || m->n_spawners) ? m->d_halo : nullptr, m->d_row_count, row0,
                                row1, m->d_live + 1, m->force_persist > 0 ? m->d_tickets : nullptr,
-                               host_knows_general ? nullptr : m->d_tickets + 8 * TICKET_STRIDE);
+                               host_knows_general ? nullptr : m->d_tickets + 8 * TICKET_STRIDE, m->place_ablate);
             m->tickets_fresh = true;
+#ifdef PEDONI_DIAGNOSTICS
+            if (m->place_ablate & 256u)      // (probe: the same body a second time under another name, with the
+                                             // switches of bits 16 and up: 128 = returning at once)
+                hipLaunchKernelGGL(place_kernel_probe, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
+                                   m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
+                                   m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
+                                   nullptr, m->d_row_count, row0, row1, m->d_live + 1, nullptr, nullptr,
+                                   (m->place_ablate >> 16) ? (m->place_ablate >> 16) : 128u);
+            if (m->place_ablate & 4096u) {   // (probes: the signature reading one / all of its arguments)
+                hipLaunchKernelGGL(place_reads_one, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
+                                   m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
+                                   m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
+                                   (HaloIn*)nullptr, m->d_row_count, row0, row1, m->d_live + 1, (uint32_t*)nullptr, (uint32_t*)nullptr, 128u);
+                hipLaunchKernelGGL(place_reads_all, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
+                                   m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
+                                   m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
+                                   (HaloIn*)nullptr, m->d_row_count, row0, row1, m->d_live + 1, (uint32_t*)nullptr, (uint32_t*)nullptr, 128u);
+            }
+            if (m->place_ablate & 2048u)     // (probe: place_kernel's signature, empty body, same grid and arguments)
+                hipLaunchKernelGGL(place_signature_only, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
+                                   m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
+                                   m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
+                                   (HaloIn*)nullptr, m->d_row_count, row0, row1, m->d_live + 1, (uint32_t*)nullptr, (uint32_t*)nullptr, 128u);
+            if (m->place_ablate & 1024u)     // (probe: a two-argument empty kernel on the same grid)
+                hipLaunchKernelGGL(probe_empty_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0, m->stream, m->d_slots, 1u);
+            if (m->place_ablate & 512u)      // (probe: a grid of 64 workgroups, returning at once)
+                hipLaunchKernelGGL(place_kernel, dim3(64), dim3(bs), 0,
+                                   m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
+                                   m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
+                                   nullptr, m->d_row_count, row0, row1, m->d_live + 1, nullptr, nullptr, 128u);
+#endif
         }
         if (host_knows_general) {
             Timed t(m, PEDONI_K_REORDER);
@@ -1801,8 +1834,7 @@ int pedoni_hip_debug_set_ablate(PedoniModel* m, uint32_t bits)
 {
     TRY(bind(m));
     m->ablate = (int)(bits & 0xffu);
-    const int place_bits = (int)(bits >> 8);              // bits 8-10: place_kernel's switches (kernels.hpp g_place_ablate)
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pedoni::g_place_ablate), &place_bits, sizeof place_bits));
+    m->place_ablate = bits >> 8;                          // bits 8 and up: place_kernel's switches (kernels.hpp PLACE_ABLATE)
     m->graph_valid = false;
     return PEDONI_OK;
 }
