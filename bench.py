@@ -36,6 +36,7 @@ DENSITY = 1.0                      # agents / m^2
 BYTES_FORCE = 40                   # 24 B read + 16 B written per agent
 BYTES_TICK = 88                    # + sort/reorder pass 24 R + 24 W
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
+SETTLE_TICKS = 58                  # untimed ticks every run has done before its warmup (see main)
 
 
 def box_geometry(width: float, height: float, wall_w: float = 0.2, margin: float = 10.0):
@@ -375,7 +376,8 @@ def main() -> None:
     width, height = side, side * G
     obstacles, waypoints = box_geometry(width, height)
     workload = (f"uniform crowd N={n_per * G:.0e} ({n_per:.0e}/GPU) in a {width:.0f}x{height:.0f} m box, "
-                f"rho={density:g}/m^2, neighbor grid 1.4 m, field maps 0.25 m, fp32").replace("e+0", "e")
+                f"rho={density:g}/m^2, neighbor grid 1.4 m, field maps 0.25 m, fp32; "
+                f"{SETTLE_TICKS} untimed ticks old at the warmup for every N").replace("e+0", "e")
 
     custom_crowd = None
     if args.workload != "c3":
@@ -430,6 +432,7 @@ def main() -> None:
     exchange = None
     runner = shard = None
     verified = None
+    crowd_age = 0          # ticks the crowd has been through before the warmup
     if sharded:
         assert model.neighbor_grid_shape()[0] == rows
         cap = default_halo_cap(int(width * 1.4 * density))
@@ -494,6 +497,7 @@ def main() -> None:
                     model.append(pos, dest, v0, vel)
                     shard.begin()
                     shard.tick_n(4); shard.set_overlap(True); shard.tick_n(4); shard.set_overlap(False)
+                    crowd_age += 8
                     torch.cuda.synchronize()
                 except Exception as e:             # noqa: BLE001
                     ok, why = 0, str(e)
@@ -560,6 +564,7 @@ def main() -> None:
             torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()   # (the library's exchanges drained before torch's collective starts)
             t0 = time.perf_counter()
             shard.tick_n(20)
+            crowd_age += 25
             torch.cuda.synchronize()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctl)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -568,12 +573,23 @@ def main() -> None:
         shard.set_overlap(use_overlap)
         exchange += (f"; tick form: {'overlapped' if use_overlap else 'plain'} "
                      f"(probe: plain {mode_ms[False] * 1e3:.0f} us, overlapped {mode_ms[True] * 1e3:.0f} us per tick; "
-                     "verification + probe = 58 ticks before the warmup, so the timed crowd is 58 ticks older than a 1-GPU run's)")
+                     f"verification + probe = {crowd_age} ticks before the warmup)")
     elif runner is not None:
         step_fn = runner.tick_n
     else:
         model.append(pos, dest, v0, vel)
         step_fn = model.tick_n
+
+    # Every configuration times a crowd of the same age.  The N > 1 runs have ticked theirs already
+    # (verification + tick-form probe); all runs tick on, untimed, to SETTLE_TICKS before the warmup.
+    # It matters: the crowd starts as independent uniform positions (agents centimetres apart), the
+    # first ~100 ticks push those apart and the tick gets ~10 % cheaper on the way
+    # (tools/short_run_cost.py) -- a 1-GPU line on a fresh crowd beside N-GPU lines on a 58-tick-old
+    # one would flatter the scaling curve.
+    if crowd_age < SETTLE_TICKS:
+        stage("settling the crowd", 60.0 + 0.05 * (SETTLE_TICKS - crowd_age) * max(1.0, n_per / 1e6))
+        step_fn(SETTLE_TICKS - crowd_age)
+        crowd_age = SETTLE_TICKS
 
     def barrier():
         # (drain first: in the overlapped form an exchange of the library's own communicator may still be
@@ -640,7 +656,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "agents_total": int(round(agents_total)),
-                       "math_mode": args.math,
+                       "math_mode": args.math, "crowd_age_at_warmup_ticks": crowd_age,
                        "parallelism": (f"row-bands x{G} ({ranks_seen} ranks answered the first all-reduce); {exchange}"
                                        if sharded else "single GPU"),
                        "field_build_s": round(t_field, 2), "field": field_how,
@@ -694,7 +710,7 @@ def main() -> None:
             fm = abi.HipModel(fopt, (width, height), field.distance_map, field.potential_maps, field.unit,
                               obstacles, device=local_rank)
             fm.append(pos, dest, v0, vel)
-            fm.tick_n(args.warmup)
+            fm.tick_n(crowd_age + args.warmup)
             fm.synchronize()
             nb = fm.get_pedestrian_count()
             fm.profile(True, kernels=[abi.K_FORCE], every=every)

@@ -211,13 +211,17 @@ struct PedoniModel {
     int force_group_slots = 0;  // PEDONI_FORCE_GROUP_SLOTS: queue depth of the group kernel (4, 6, 8; unset = 6)
 
     // steady-state tick pair captured as a hipGraph (pedoni_hip_tick_n); see tick_graph()
-    hipGraphExec_t graph_exec = nullptr;
-    bool graph_valid = false;
+    // one captured tick pair per tick parity (the ping-pong buffers a pair starts from): a run that
+    // mixes eager ticks in (every n-th tick event-timed, n odd) starts its pairs on both
+    struct TickGraph {
+        hipGraphExec_t exec = nullptr;
+        bool valid = false;
+        uint32_t n_upper = 0, base = 0;
+        int pv = 0, vd = 0, cs = 0, sk = 0;
+        hipStream_t stream = nullptr;
+    } graphs[2];
+    void drop_graphs() { graphs[0].valid = graphs[1].valid = false; }
     bool use_graph = true;     // PEDONI_NO_GRAPH=1: always launch eagerly
-    uint32_t graph_n_upper = 0, graph_base = 0;
-    int graph_pv = 0, graph_vd = 0, graph_cs = 0, graph_sk = 0;
-    uint32_t graph_parity = 0;
-    hipStream_t graph_stream = nullptr;
 
     // profiling
     uint32_t profile_mask = 0;
@@ -363,7 +367,7 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
     }
     m->have_old = false; // the per-agent old-cell array did not survive the reallocation
     m->keys_valid = false;
-    m->graph_valid = false;
+    m->drop_graphs();
     m->cap = ncap;
     return PEDONI_OK;
 }
@@ -1149,7 +1153,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     if (m->ev_sorted) hipEventDestroy(m->ev_sorted);
     if (m->ev_interior) hipEventDestroy(m->ev_interior);
     for (hipEvent_t e : m->ev_tick) if (e) hipEventDestroy(e);
-    if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
+    for (auto& g : m->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     if (m->own_stream) hipStreamDestroy(m->own_stream);
     delete m;
 }
@@ -1233,41 +1237,66 @@ bool graphable(const PedoniModel* m)
            m->grid.rows <= 0xffff && m->grid.cols <= 0xffff;
 }
 
+// Records `ticks` ticks from the current host state; with `keep` the recording becomes that parity's
+// replayable pair, without it only the host bookkeeping advances (nothing runs on the device).
+int capture_ticks(PedoniModel* m, int ticks, PedoniModel::TickGraph* keep)
+{
+    const uint32_t n_upper = m->n_upper, base = m->base, parity = m->tick_parity & 1u;
+    const int pv = m->pv, vd = m->vd, cs = m->cs, sk = m->sk;
+    HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    int rc = PEDONI_OK;
+    for (int t = 0; t < ticks && rc == PEDONI_OK; ++t) {
+        rc = sort_despawn(m);
+        if (rc == PEDONI_OK) rc = update_states(m);
+    }
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(m->stream, &graph);
+    if (rc != PEDONI_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(PEDONI_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    if (!keep) { hipGraphDestroy(graph); return PEDONI_OK; }
+    e = hipGraphInstantiate(&keep->exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) { keep->exec = nullptr; return fail(PEDONI_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    // the capture ran the host bookkeeping of two ticks: the indices are back at the key
+    if (m->pv != pv || m->vd != vd || m->cs != cs || m->sk != sk || (m->tick_parity & 1u) != parity ||
+        m->n_upper != n_upper)
+        return fail(PEDONI_E_HIP, "tick graph: host state did not return after two ticks");
+    keep->n_upper = n_upper; keep->base = base; keep->pv = pv; keep->vd = vd; keep->cs = cs; keep->sk = sk;
+    keep->stream = m->stream;
+    keep->valid = true;
+    return PEDONI_OK;
+}
+
+bool graph_matches(const PedoniModel* m, const PedoniModel::TickGraph& g)
+{
+    return g.valid && g.exec && g.n_upper == m->n_upper && g.base == m->base && g.pv == m->pv && g.vd == m->vd &&
+           g.cs == m->cs && g.sk == m->sk && g.stream == m->stream;
+}
+
 int tick_graph_pair(PedoniModel* m)
 {
-    const bool match = m->graph_valid && m->graph_exec && m->graph_n_upper == m->n_upper &&
-                       m->graph_base == m->base && m->graph_pv == m->pv && m->graph_vd == m->vd &&
-                       m->graph_cs == m->cs && m->graph_sk == m->sk &&
-                       m->graph_parity == (m->tick_parity & 1u) && m->graph_stream == m->stream;
-    if (!match) {
-        if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-        m->graph_valid = false;
-        const uint32_t n_upper = m->n_upper, base = m->base, parity = m->tick_parity & 1u;
-        const int pv = m->pv, vd = m->vd, cs = m->cs, sk = m->sk;
-        HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
-        int rc = PEDONI_OK;
-        for (int t = 0; t < 2 && rc == PEDONI_OK; ++t) {
-            rc = sort_despawn(m);
-            if (rc == PEDONI_OK) rc = update_states(m);
+    const uint32_t parity = m->tick_parity & 1u;
+    PedoniModel::TickGraph& g = m->graphs[parity];
+    if (!graph_matches(m, g)) {
+        if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        g.valid = false;
+        TRY(capture_ticks(m, 2, &g));
+        // the pair that starts one tick later, while we are at it: a caller that mixes single ticks
+        // in (every n-th tick event-timed) then never meets a capture + instantiate in mid-run
+        PedoniModel::TickGraph& o = m->graphs[parity ^ 1u];
+        if (!(o.valid && o.exec && o.n_upper == m->n_upper && o.base == m->base && o.stream == m->stream)) {
+            if (o.exec) { hipGraphExecDestroy(o.exec); o.exec = nullptr; }
+            o.valid = false;
+            TRY(capture_ticks(m, 1, nullptr));
+            TRY(capture_ticks(m, 2, &o));
+            TRY(capture_ticks(m, 1, nullptr));
+            if ((m->tick_parity & 1u) != parity || !graph_matches(m, g))
+                return fail(PEDONI_E_HIP, "tick graph: host state did not return after the second capture");
         }
-        hipGraph_t graph = nullptr;
-        hipError_t e = hipStreamEndCapture(m->stream, &graph);
-        if (rc != PEDONI_OK) { if (graph) hipGraphDestroy(graph); return rc; }
-        if (e != hipSuccess) return fail(PEDONI_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        e = hipGraphInstantiate(&m->graph_exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
-        if (e != hipSuccess) { m->graph_exec = nullptr; return fail(PEDONI_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
-        // the capture ran the host bookkeeping of two ticks: the indices are back at the key
-        if (m->pv != pv || m->vd != vd || m->cs != cs || m->sk != sk || (m->tick_parity & 1u) != parity ||
-            m->n_upper != n_upper)
-            return fail(PEDONI_E_HIP, "tick graph: host state did not return after two ticks");
-        m->graph_n_upper = n_upper; m->graph_base = base; m->graph_pv = pv; m->graph_vd = vd;
-        m->graph_cs = cs; m->graph_sk = sk; m->graph_parity = parity; m->graph_stream = m->stream;
-        m->graph_valid = true;
     }
     {
         Range replay("tick pair (captured graph replay)");
-        HIP_TRY(hipGraphLaunch(m->graph_exec, m->stream));
+        HIP_TRY(hipGraphLaunch(g.exec, m->stream));
     }
     // host state after a pair of ticks == before it (see above); the flags the eager path
     // would have left: keys fused, counts pending, order not sorted
@@ -1316,7 +1345,7 @@ int pedoni_hip_set_spawners(PedoniModel* m, const PedoniSpawner* spawners, uint3
         return fail(PEDONI_E_INVALID, "set_spawners: device spawning needs the neighbor grid "
                                       "(the brute-force option path spawns on the host)");
     HIP_TRY(hipStreamSynchronize(m->stream));
-    m->graph_valid = false;
+    m->drop_graphs();
     if (m->n_spawners) { // hand the desired-speed stream back to the host side
         SpawnState st{};
         HIP_TRY(hipMemcpy(&st, m->d_spawn_state, sizeof st, hipMemcpyDeviceToHost));
@@ -1484,7 +1513,7 @@ int pedoni_hip_clear(PedoniModel* m)
     m->have_old = false;
     m->keys_valid = false;
     m->sorted = false;
-    m->graph_valid = false;       // the captured tick pair bakes in band, bounds and buffers
+    m->drop_graphs();       // the captured tick pair bakes in band, bounds and buffers
     return PEDONI_OK;
 }
 
@@ -1536,7 +1565,7 @@ int pedoni_hip_set_stream(PedoniModel* m, void* hip_stream, int32_t use_library_
     TRY(drain_events(m));
     HIP_TRY(hipStreamSynchronize(m->stream));
     m->stream = use_library_stream ? m->own_stream : (hipStream_t)hip_stream;
-    m->graph_valid = false;
+    m->drop_graphs();
     return PEDONI_OK;
 }
 
@@ -1559,6 +1588,14 @@ int pedoni_hip_profile(PedoniModel* m, int32_t enable)
     TRY(bind(m));
     TRY(drain_events(m));
     m->profile_mask = (uint32_t)enable & ((1u << PEDONI_N_KERNELS) - 1u);
+    // the event pairs of the first timed ticks exist before those ticks run (creating them between
+    // the launches of a tick puts the host behind the device)
+    while (m->profile_mask && m->ev_pool.size() < 256) {
+        EventPair p{};
+        HIP_TRY(hipEventCreate(&p.a));
+        if (hipEventCreate(&p.b) != hipSuccess) { hipEventDestroy(p.a); return fail(PEDONI_E_HIP, "hipEventCreate failed"); }
+        m->ev_pool.push_back(p);
+    }
     return PEDONI_OK;
 }
 
@@ -1594,7 +1631,7 @@ int pedoni_hip_set_band(PedoniModel* m, int32_t row_begin, int32_t row_end, uint
     m->band_hi = row_end;
     m->halo_cap = halo_cap;
     m->base = halo_cap;
-    m->graph_valid = false;       // (band_lo / band_hi are arguments of the captured kernels)
+    m->drop_graphs();       // (band_lo / band_hi are arguments of the captured kernels)
     TRY(ensure_capacity(m, m->base + std::max<uint32_t>(m->opt.initial_capacity, 1024)));
     return pedoni_hip_clear(m);
 }
@@ -1835,7 +1872,7 @@ int pedoni_hip_debug_set_ablate(PedoniModel* m, uint32_t bits)
     TRY(bind(m));
     m->ablate = (int)(bits & 0xffu);
     m->place_ablate = bits >> 8;                          // bits 8 and up: place_kernel's switches (kernels.hpp PLACE_ABLATE)
-    m->graph_valid = false;
+    m->drop_graphs();
     return PEDONI_OK;
 }
 #endif // PEDONI_DIAGNOSTICS

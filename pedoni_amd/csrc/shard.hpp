@@ -344,7 +344,7 @@ int recut_apply(PedoniShard* s, const std::vector<int32_t>& nb)
     m->keys_valid = false;          // every stored agent is keyed afresh against the new band
     m->halo_keys_done = false;
     m->sorted = false;
-    m->graph_valid = false;
+    m->drop_graphs();
     TRY(sort_despawn(m));
     s->recuts += 1;
     return PEDONI_OK;
