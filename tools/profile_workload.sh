@@ -10,7 +10,10 @@ rm -rf "$OUT"; mkdir -p "$OUT/st"
 export TMPDIR=/tmp
 cd /tmp
 B="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-profile --no-fast-leg --workload $WL"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B > "$OUT/stats.log" 2>&1 || echo "stats pass failed"
+# the stats pass traces the driver's own command (event timing on, so that the run's line can be set beside the trace)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 \
+    --no-cpu-baseline --no-fast-leg --workload $WL > "$OUT/stats.log" 2>&1 || echo "stats pass failed"
+grep '^{' "$OUT/stats.log" > "$OUT/stats_bench.json"
 echo "stats done"
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/fetch" -- $B > "$OUT/fetch.log" 2>&1 || echo "fetch pass failed"
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/write" -- $B > "$OUT/write.log" 2>&1 || echo "write pass failed"
@@ -28,6 +31,7 @@ cd "$ROOT"
 python3 bench.py --no-cpu-baseline --workload $WL --steps 100 --warmup 10 > "$OUT/bench.json" 2> "$OUT/bench.err"
 python3 tools/pmc_summary.py "$TAG" "$OUT/stats" "$OUT/fetch" "$OUT/write" - "$OUT/bench.json" > "$OUT/pmc_summary.txt"
 python3 tools/stall_summary.py "$TAG" "$OUT/st" > "$OUT/stall_summary.txt"
+python3 tools/timed_region_stats.py "$TAG" "$OUT/stats" "$OUT/stats_bench.json" > "$OUT/timed_region.txt" || echo "timed-region summary failed"
 cp "$OUT/bench.json" profiles/${TAG}_bench.json
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
 ls gpurun_out/profiles_$TAG
