@@ -273,10 +273,16 @@ int pedoni_shard_tick_n(PedoniShard* s, uint32_t steps);
 int pedoni_shard_owned_count(PedoniShard* s, int32_t* count);
 int pedoni_shard_band(PedoniShard* s, int32_t* row_begin, int32_t* row_end);
 /* on: the exchange of the NEXT tick's lists runs on a stream of its own while this tick's interior
- * rows are still being computed (the tick is split: rows beside the band's edges, pack, send;
- * then the interior).  Same results bit for bit; pays once the exchange costs more than the
- * split does (two more launches, cross-stream waits) -- bench.py times both and keeps the faster. */
+ * rows are still being computed: the force launch takes the tiles of the rows beside the band's edges
+ * first and releases pack + send from inside the launch (small bands: an edge launch, pack, send; then
+ * the interior launch).  Same results bit for bit; pays once the exchange costs more than the ~6 us of
+ * the cross-stream join -- bench.py times both and keeps the faster. */
 int pedoni_shard_set_overlap(PedoniShard* s, int32_t on);
+/* [ext] how the overlapped ticks so far were run: `edge_first` counts those whose ONE force launch took
+ * the edge rows' tiles first and released the exchange from inside the launch, `split` those run as an
+ * edge launch + an interior launch (small bands on the G-lanes-per-agent kernels, PEDONI_SHARD_FORM=split),
+ * `plain` every other tick (overlap off, band too thin to split, re-cut ticks). */
+int pedoni_shard_tick_forms(PedoniShard* s, uint32_t* edge_first, uint32_t* split, uint32_t* plain);
 /* a token ring through the very ncclSend / ncclRecv pair the exchange uses (self-addressed at
  * the outer bands): PEDONI_OK iff both neighbours' tokens arrived */
 int pedoni_shard_selftest(PedoniShard* s);

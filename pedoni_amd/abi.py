@@ -43,7 +43,7 @@ SYMBOLS = [
     "pedoni_hip_create_rows", "pedoni_shard_map_rows", "pedoni_hip_eikonal",
     "pedoni_shard_unique_id", "pedoni_shard_balanced_bounds", "pedoni_shard_recut_bounds", "pedoni_shard_create", "pedoni_shard_destroy",
     "pedoni_shard_begin", "pedoni_shard_tick_n", "pedoni_shard_owned_count", "pedoni_shard_band",
-    "pedoni_shard_selftest", "pedoni_shard_set_rebalance", "pedoni_shard_set_overlap", "pedoni_shard_local_group_tick_n",
+    "pedoni_shard_selftest", "pedoni_shard_set_rebalance", "pedoni_shard_set_overlap", "pedoni_shard_tick_forms", "pedoni_shard_local_group_tick_n",
 ]
 
 
@@ -555,6 +555,12 @@ class Shard:
     def set_overlap(self, on: bool) -> None:
         """Exchange of the next tick's lists on its own stream, under the interior rows' update."""
         _check(self._lib, self._lib.pedoni_shard_set_overlap(self._h, C.c_int32(1 if on else 0)))
+
+    def tick_forms(self) -> dict:
+        """How the ticks so far were run: {'edge_first', 'split', 'plain'} (pedoni_shard_tick_forms)."""
+        e, sp, pl = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _check(self._lib, self._lib.pedoni_shard_tick_forms(self._h, C.byref(e), C.byref(sp), C.byref(pl)))
+        return {"edge_first": int(e.value), "split": int(sp.value), "plain": int(pl.value)}
 
     def set_rebalance(self, every_ticks: int, max_rows_per_step: int = 4, map_slack_rows: int = -1) -> None:
         _check(self._lib, self._lib.pedoni_shard_set_rebalance(self._h, C.c_uint32(every_ticks),

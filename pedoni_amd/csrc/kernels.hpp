@@ -90,6 +90,7 @@ __device__ __forceinline__ uint32_t pack_cell(uint32_t cx, uint32_t cy) { return
 // returns PEDONI_E_HIP / PEDONI_E_CAPACITY while a bit is set -- nothing continues silently.
 constexpr uint32_t STATUS_SCAN_MISMATCH = 1u; // a row's cell counts do not add up to its row count
 constexpr uint32_t STATUS_LIVE_OVERFLOW = 2u; // more live agents than the host's bound of the arrays
+constexpr uint32_t STATUS_EDGE_WAIT = 8u;     // edge_wait_kernel gave up: the edge-first force launch never signalled
 
 // Every stored key is followed by one count on its cell AND one on its grid row: the scan
 // (scan_rows_kernel) turns the row totals into each row's first index without any
@@ -693,6 +694,16 @@ struct ForceArgs {
     SortFlags* flags;
     uint32_t parity_next;
     int32_t xcd_remap; // XCD-contiguous block order (PEDONI_NO_XCD_REMAP=1 turns it off)
+    // edge-first form (force_kernel_queue_edge_first, a band of a sharded run): the tiles holding the agents
+    // of the rows below edge_row[0] and from edge_row[1] up are worked on by the FIRST workgroups; when
+    // the last of those has stored its results, edge_flag (a device word another stream's edge_wait_kernel
+    // polls) is set to edge_seq
+    int32_t edge_row[2];
+    uint32_t edge_blocks[2];   // hint: workgroups started first for the low / the high edge rows ...
+    uint32_t edge_tile_hi;     // ... the latter on tiles [edge_tile_hi, edge_tile_hi + edge_blocks[1])
+    uint32_t* edge_counter;
+    uint32_t* edge_flag;
+    uint32_t edge_seq;
     uint32_t* tickets;  // persistent form: 8 ticket words, TICKET_STRIDE apart (zeroed by the place kernel)
     uint32_t n_tiles;   // persistent form: 64-agent tiles of this launch
     unsigned long long* trace; // TRACE build only (7 words, see force_queue_body)
@@ -869,9 +880,15 @@ constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 // WALL time goes, waiting and being passed over by the arbiter included.
 // One tile = the 64 agents of one wave: sorted indices base + 64 * tile + lane.  `queue` / `who` are
 // the calling wave's own LDS queue, `tab` the block's copy of the exp table.
-template <int MODE, int SLOTS, bool TRACE = false, bool ABL = false>
+// EXIT: called by every lane exactly once, where it leaves the tile (the lanes of a wave leave at up to four
+// places; nothing runs after the tile function that would need them back together -- the mask to restore
+// would be two more SGPRs held across the whole tile, which at the 7-wave budget spills).  The default does nothing.
+struct NoExit { __device__ __forceinline__ void operator()() const {} };
+
+template <int MODE, int SLOTS, bool TRACE = false, bool ABL = false, class EXIT = NoExit>
 __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint32_t t0, float2* __restrict__ queue,
-                                                 uint32_t* __restrict__ who, const uint64_t* __restrict__ tab)
+                                                 uint32_t* __restrict__ who, const uint64_t* __restrict__ tab,
+                                                 const EXIT on_exit = EXIT{})
 {
     unsigned long long tr_t0 = 0, tr_mark = 0, tr_acc[5] = {0, 0, 0, 0, 0};
     auto tr_lap = [&](int which) {
@@ -1054,7 +1071,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
     }
     // (the epilogue below runs per lane; the trace is flushed by lane 0 wherever it leaves)
     if (!valid) {
-        tr_flush();
+        tr_flush(); on_exit();
         return;
     }
     if (ghost) {                                                  // ghost row: never integrated
@@ -1064,7 +1081,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
             a.velx_out[id] = vv;
             if (a.key_next) a.key_next[id] = DEAD;
         }
-        tr_flush();
+        tr_flush(); on_exit();
         return;
     }
 
@@ -1080,7 +1097,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
     else if (a.use_distance_map) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
     else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
 
-    if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); tr_flush(); return; }
+    if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); tr_flush(); on_exit(); return; }
 
     // integrator, sfm.rs:245-254
     v2 vel_prev = vel;
@@ -1113,7 +1130,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
         else if (ABL && (a.ablate & 128)) { if (k == 0xfffffffeu) atomicAdd(&a.cell_count[k], 1u); }   // (no counts at all)
         else count_key(a.cell_count, a.row_count, k != DEAD, k, (uint32_t)cy);
     }
-    tr_flush();
+    tr_flush(); on_exit();
 }
 
 // LDS of one force-kernel block: the exp table and one pair queue per wave
@@ -1477,6 +1494,125 @@ force_kernel_queue_s94(ForceArgs a)
 {
     force_queue_body<MODE, SLOTS>(a);
 }
+
+// ---- K_FORCE of a band, edge rows first (the overlapped tick of a sharded run) --------------------
+// One launch over the whole band, as the plain tick's -- but the workgroups the hardware starts first
+// take the tiles of the band's edge rows (the head and the tail of the sorted order), and the wave
+// that completes the last of those tiles says so in a word of device memory.  The shard's
+// communication stream waits on that word (edge_wait_kernel below) and packs and sends the updated
+// edge rows under the rest of this launch: no second force launch, no event between two launches on
+// the model's stream.
+//   hardware block b <  e_lo          -> tile b                         (the head of the sorted order)
+//   e_lo <= b < e_lo + e_hi           -> tile t_hi + (b - e_lo)         (around the end of the live agents)
+//   the others                        -> the tiles left, in order, XCD-contiguous as ever
+// That placement is a HINT from the host (edge_blocks / edge_tile_hi: where the lists' capacity and its own
+// bound of the live count put the edge rows) and a speed matter only.  Which workgroups really hold edge
+// agents, and how many there are, each workgroup reads off cell_start and the live count AFTER its tile
+// (off the path to its first load: read before the tile they cost every wave one more dependent latency,
+// force kernel 91 against 87 us): an edge workgroup releases its records and counts itself in, the one
+// that completes the count stores the flag.  One release per edge WORKGROUP, and as few of those as there
+// are: at agent scope it writes back the XCD's whole L2 (126 blocks per side hinted AND signalling, one
+// release per wave: force kernel 118 us).  Every launch stores the flag: with no edge agent at all,
+// workgroup 0 does.
+__device__ __forceinline__ uint32_t edge_first_tile(uint32_t b, uint32_t n_blocks, uint32_t e_lo, uint32_t e_hi, uint32_t t_hi,
+                                                    int32_t remap)
+{
+    const uint32_t n_edge = e_lo + e_hi;
+    if (b < e_lo) return b;
+    if (b < n_edge) return t_hi + (b - e_lo);
+    // the i-th tile that is neither in [0, e_lo) nor in [t_hi, t_hi + e_hi)
+    const uint32_t i = remap ? xcd_contiguous_block(b - n_edge, n_blocks - n_edge) : b - n_edge;
+    const uint32_t t = e_lo + i;
+    return t < t_hi ? t : t + e_hi;
+}
+
+struct EdgeEpilogue {       // what the workgroup's last lanes need when they leave the tile, parked in LDS before it
+    const uint32_t* lo_end;   // &cell_start[edge_row[0] * cols]
+    const uint32_t* hi_begin; // &cell_start[edge_row[1] * cols]
+    const uint32_t* live;
+    uint32_t* counter;
+    uint32_t* flag;
+    uint32_t base, seq, tile, first_block, lanes_out;
+};
+
+// (see NoExit) the lanes that leave the tile together count themselves out of the workgroup; those that
+// complete the count speak for it: an edge workgroup releases its records and counts itself in, the
+// workgroup that completes THAT count stores the flag
+struct EdgeExit {
+    EdgeEpilogue* ep;
+    __device__ __forceinline__ void operator()() const
+    {
+        const unsigned long long here = __ballot(1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // these lanes' records are out
+        if (__builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u)) != 0u) return;
+        const uint32_t n = (uint32_t)__popcll(here);
+        if (__hip_atomic_fetch_add(&ep->lanes_out, n, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + n != (uint32_t)FORCE_THREADS) return;
+        const uint32_t base = ep->base;
+        const uint32_t lo_n = *ep->lo_end - base;         // agents below edge_row[0]
+        const uint32_t hi_0 = *ep->hi_begin - base;       // first agent of edge_row[1]
+        const uint32_t live = *ep->live - base;
+        // edge workgroups: tiles [0, t_lo) and [t_h0, t_h1), the second run cut where it overlaps the first
+        const uint32_t T = (uint32_t)FORCE_THREADS;
+        const uint32_t t_lo = (lo_n + T - 1u) / T;
+        uint32_t t_h0 = hi_0 / T, t_h1 = live > hi_0 ? (live + T - 1u) / T : t_h0;
+        t_h0 = max(t_h0, t_lo); t_h1 = max(t_h1, t_h0);
+        const uint32_t expected = t_lo + (t_h1 - t_h0);
+        const uint32_t tile = ep->tile;
+        const bool mine = expected ? (tile < t_lo || (tile >= t_h0 && tile < t_h1)) : ep->first_block != 0u;
+        if (!mine) return;
+        __threadfence();              // release (agent scope): the workgroup's records, before it counts itself in
+        uint32_t* counter = ep->counter;
+        if (atomicAdd(counter, 1u) + 1u == max(expected, 1u)) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+            __hip_atomic_store(ep->flag, ep->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+};
+
+template <int MODE, int SLOTS>
+__device__ __forceinline__ void force_edge_first_body(const ForceArgs& a)
+{
+    __shared__ EdgeEpilogue ep;
+    const uint32_t tile = edge_first_tile(blockIdx.x, gridDim.x, a.edge_blocks[0], a.edge_blocks[1], a.edge_tile_hi, a.xcd_remap);
+    if (threadIdx.x == 0) {
+        ep.lo_end = a.cell_start + (int64_t)a.edge_row[0] * a.grid.cols;
+        ep.hi_begin = a.cell_start + (int64_t)a.edge_row[1] * a.grid.cols;
+        ep.live = a.live_count;
+        ep.counter = a.edge_counter;
+        ep.flag = a.edge_flag;
+        ep.base = a.base; ep.seq = a.edge_seq; ep.tile = tile; ep.first_block = blockIdx.x == 0 ? 1u : 0u;
+        ep.lanes_out = 0;
+    }
+    PEDONI_FORCE_LDS(SLOTS);          // (its barrier publishes `ep` too)
+    const uint32_t wave = threadIdx.x >> 6;
+    force_queue_tile<MODE, SLOTS, false, false, EdgeExit>(a, tile * blockDim.x + threadIdx.x, queue_all[wave], who_all[wave], tab,
+                                                          EdgeExit{&ep});
+}
+
+// The other stream's side of it: one wave that looks at the word every ~2 us (s_sleep between two agent-scope
+// loads: no traffic to speak of) and ends when it reads this tick's number -- or after `limit` ticks of the
+// 100 MHz clock, raising STATUS_EDGE_WAIT, so that the wave ends whatever happens to the launch it waits for.
+// (hipStreamWaitValue32 does work here -- tools/microbench/stream_wait_value.hip -- but the runtime
+// implements it as a kernel that polls without pause: with it in flight the place kernel took 26 us
+// instead of 18.5 and the force kernel 103 instead of 92, profiles/r03_shard_timeline.txt.)
+__global__ void __launch_bounds__(64) edge_wait_kernel(const uint32_t* flag, uint32_t seq, uint32_t* status,
+                                                       unsigned long long limit)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const uint32_t seen = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)(seen - seq) >= 0) return;
+        if (wall_clock64() - t0 > limit) { atomicOr(status, STATUS_EDGE_WAIT); return; }
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_edge_first_s94(ForceArgs a) { force_edge_first_body<MODE, SLOTS>(a); }
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_edge_first(ForceArgs a) { force_edge_first_body<MODE, SLOTS>(a); }
 
 #ifdef PEDONI_DIAGNOSTICS
 // ---- K_FORCE, persistent-wave forms: a MEASURED DEAD END, kept in the diagnostics build only -----

@@ -222,6 +222,10 @@ struct PedoniModel {
     } graphs[2];
     void drop_graphs() { graphs[0].valid = graphs[1].valid = false; }
     bool use_graph = true;     // PEDONI_NO_GRAPH=1: always launch eagerly
+    // edge-first force launch of a band (launch_force part 3; set by the shard driver, shard.hpp)
+    uint32_t* edge_counter = nullptr;   // device word
+    uint32_t* edge_flag = nullptr;      // device word
+    uint32_t edge_seq = 0;
 
     // profiling
     uint32_t profile_mask = 0;
@@ -648,7 +652,8 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
     return a;
 }
 
-// part: 0 = every sorted agent; 1 = the rows next to the band's edges (ghost rows, which
+// part: 0 = every sorted agent; 3 = the same in ONE launch whose first workgroups take the edge rows and
+// signal their completion (force_kernel_queue_edge_first); 1 = the rows next to the band's edges (ghost rows, which
 // are only NaN-marked, and the two owned rows beside each); 2 = the interior rows.  Parts 1
 // and 2 together equal part 0; they exist so that a sharded tick can pack and send its
 // boundary agents while the interior is still being computed.
@@ -663,7 +668,23 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         const int32_t rows = m->grid.rows;
         const int32_t lo_a = std::max(m->band_lo - 1, 0), lo_b = std::min(m->band_lo + 2, m->band_hi);
         const int32_t hi_a = std::max(m->band_hi - 2, lo_b), hi_b = std::min(m->band_hi + 1, rows);
-        if (part == 1) {
+        if (part == 3) {
+            if (!m->edge_flag || !m->edge_counter) return fail(PEDONI_E_INVALID, "edge-first force launch without its signal word");
+            a.edge_row[0] = lo_b; a.edge_row[1] = hi_a;
+            a.edge_counter = m->edge_counter; a.edge_flag = m->edge_flag; a.edge_seq = m->edge_seq;
+            // where the edge rows should be (a hint: the kernel finds the real ones itself).  Three rows at
+            // either edge, each <= ~0.7 halo_cap agents; the live agents end about where the host's bound
+            // stood before the unpacks since its last reading of the count each added their capacity
+            const uint32_t nb = blocks_for(n, FORCE_THREADS), each = std::min(blocks_for(3u * std::max(m->halo_cap, 1u), FORCE_THREADS), nb / 2u);
+            const uint32_t lists = std::max(1u, (m->band_lo > 0 ? 1u : 0u) + (m->band_hi < rows ? 1u : 0u));
+            const uint64_t slack = (uint64_t)(m->ticks_since_tighten + 1u) * m->halo_cap * lists;
+            const uint32_t live_est = (uint32_t)(n > slack ? n - slack : 0u) + m->halo_cap / 2u;
+            const uint32_t end_tile = std::min(blocks_for(live_est, FORCE_THREADS), nb);
+            a.edge_blocks[0] = each;
+            a.edge_blocks[1] = std::min(each, nb - each);
+            a.edge_tile_hi = std::max(end_tile > a.edge_blocks[1] ? end_tile - a.edge_blocks[1] : 0u, each);
+            if (a.edge_tile_hi + a.edge_blocks[1] > nb) a.edge_tile_hi = nb - a.edge_blocks[1];
+        } else if (part == 1) {
             a.seg_row[0][0] = lo_a; a.seg_row[0][1] = lo_b;
             a.seg_row[1][0] = hi_a; a.seg_row[1][1] = hi_b;
             n = std::min(n, 8u * std::max(m->halo_cap, 1u)); // 6 rows, each <= ~0.7 halo_cap
@@ -684,6 +705,20 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
         // (few waves per SIMD anyway) run the default build with 8-slot batches.  PEDONI_FORCE_SLOTS overrides:
         // 4 / 5 (s94), 6, 8, 15 (5 slots, default SGPRs), 16 / 18 (s94 with 6 / 8 slots).
         const ForcePlan c = plan_force(m, n, part != 2);
+        if (part == 3) {
+            // (the caller has checked that the plan is a one-lane-per-agent build: edge_first_ready)
+            if (c.group > 1 || (c.build == ForceBuild::S94 && c.slots != 6) || (c.build != ForceBuild::S94 && c.slots != 8))
+                return fail(PEDONI_E_INVALID, "edge-first force launch: no such build of the kernel");
+            if (c.build == ForceBuild::S94) {
+                if (fast) hipLaunchKernelGGL((force_kernel_queue_edge_first_s94<1, 6>), grid, block, 0, stream, a);
+                else hipLaunchKernelGGL((force_kernel_queue_edge_first_s94<0, 6>), grid, block, 0, stream, a);
+            } else {
+                if (fast) hipLaunchKernelGGL((force_kernel_queue_edge_first<1, 8>), grid, block, 0, stream, a);
+                else hipLaunchKernelGGL((force_kernel_queue_edge_first<0, 8>), grid, block, 0, stream, a);
+            }
+            HIP_TRY(hipGetLastError());
+            return PEDONI_OK;
+        }
 #ifdef PEDONI_DIAGNOSTICS
         // diagnostic instantiations (per-phase trace, ablation switches): a build of their own
         if (m->d_trace && c.group > 1) {       // per-wave records of the group kernel (tools/group_trace.py)
@@ -798,6 +833,18 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
     return PEDONI_OK;
 }
 
+// can the band's next force launch take the edge-first form?  (a one-lane-per-agent build of the
+// queue kernel in its default batch size, something to launch, the signal word in place)
+bool edge_first_ready(PedoniModel* m)
+{
+    if (!m->edge_flag || !m->edge_counter || m->n_upper <= m->base || !m->opt.use_neighbor_grid || m->force_simple) return false;
+#ifdef PEDONI_DIAGNOSTICS
+    if (m->d_trace || m->ablate || m->force_persist) return false;
+#endif
+    const ForcePlan c = plan_force(m, m->n_upper - m->base, true);
+    return c.group == 1 && ((c.build == ForceBuild::S94 && c.slots == 6) || (c.build != ForceBuild::S94 && c.slots == 8));
+}
+
 void after_update(PedoniModel* m)
 {
     if (m->n_upper > m->base) m->pv = 1 - m->pv;
@@ -830,6 +877,9 @@ int check_status(uint32_t status)
     if (status & STATUS_LIVE_OVERFLOW)
         return fail(PEDONI_E_CAPACITY, "device status: more live agents than the host's bound of the arrays "
                                        "(received lists larger than the reserved capacity?)");
+    if (status & STATUS_EDGE_WAIT)
+        return fail(PEDONI_E_HIP, "device status: the overlapped band tick waited in vain for its force launch's edge rows "
+                                  "(the lists sent that tick may be incomplete)");
     if (status & STATUS_FIELD_SLICE)
         return fail(PEDONI_E_CAPACITY, "device status: an agent sampled a field-map row outside the rows uploaded "
                                        "for this band (pedoni_hip_create_rows: widen the row range)");

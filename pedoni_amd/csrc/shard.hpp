@@ -198,6 +198,12 @@ struct PedoniShard {
     bool lists_ready = false;   // the receive buffers already hold this tick's lists
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_recv = nullptr;
+    // edge-first overlapped tick: a device word the force launch sets when its edge tiles are done and
+    // the communication stream's edge_wait_kernel polls (null: PEDONI_SHARD_FORM=split)
+    uint32_t* d_edge_flag = nullptr;
+    uint32_t* d_edge_counter = nullptr;
+    uint32_t edge_seq = 0;
+    uint32_t n_edge_first = 0, n_split = 0, n_plain = 0;   // pedoni_shard_tick_forms
     // members of a local group (one process, one device) reach each other directly -- through the
     // caller's array, valid only inside pedoni_shard_local_group_tick_n
     PedoniShard** group = nullptr;
@@ -394,25 +400,40 @@ int shard_start_next(PedoniShard* s)
     return PEDONI_OK;
 }
 
-// Overlapped tick (round 3 form).  Everything that computes stays on the model's stream, in this order:
-// the few rows beside the band's edges FIRST (a small launch), then the interior rows (the bulk).  The
-// pack of the freshly updated edge rows and the exchange of the NEXT tick's lists leave on the shard's
-// own high-priority stream as soon as the edge rows are done, and have the whole interior launch
-// (~85 us) to complete in; the next tick joins on one event that has long fired:
+// Overlapped tick: the pack of the freshly updated edge rows and the exchange of the NEXT tick's lists
+// run on the shard's own high-priority stream under the rest of this tick's force launch; the next tick
+// joins on one event that has long fired.  Two forms.
+//
+// EDGE-FIRST (bands large enough for the one-lane-per-agent kernel; the form bench.py's 1e6-agent bands
+// run): ONE force launch over the band -- the plain tick's -- whose first workgroups take the edge rows'
+// tiles and set a device word when the last of them has released its records
+// (force_kernel_queue_edge_first); the communication stream holds a one-wave kernel that looks at that
+// word every ~2 us (edge_wait_kernel; bounded: STATUS_EDGE_WAIT after 5 s):
+//     model stream:  unpack, sort/despawn, force(edge tiles first ... interior tiles) ........  [join]
+//     comm stream :                          [wave polls word >= seq] pack, ncclSend/Recv, [record]
+// The model's stream carries exactly the plain tick's launches minus the pack: 128 us per tick against
+// 122 plain on one GPU (bench.py's probe; the ~6 us are the join, an event wait between the force
+// launch and the next unpack), the pack done 28 us into the 86-us force launch
+// (profiles/r03_shard_timeline.txt).
+//
+// SPLIT (small bands, whose force kernel is the 2-4-lanes-per-agent one; PEDONI_SHARD_FORM=split): the
+// few rows beside the band's edges FIRST (a small launch), then the interior rows (the bulk):
 //     model stream:  unpack, sort/despawn, force(edge rows) [fork] force(interior rows) ......  [join]
 //     comm stream :                                  [wait fork] pack, ncclSend/Recv, [record]
 // What it costs over the plain tick is the edge launch (8 000 agents: 9 us on the 4-lanes-per-agent
 // kernel, 15 us on the one-lane kernel) and ~7 us of event record between the two force launches:
-// 140 us per tick against 122 plain on one GPU (bench.py's probe) -- paid to take the exchange's
-// latency, whatever it is on the node, off the tick; bench.py times both forms on the node and keeps
-// the faster.  Forms measured and dropped on the way (kernel
-// timelines, profiles/r03_shard_timeline.txt; one GPU, nothing on the wire, plain tick 124-125 us):
-// round 2's (edge rows + pack on the model's stream, interior on a side stream, exchange on a third:
-// three cross-stream hops of 7-20 us each on the critical path, and a 1024-thread pack workgroup that
-// waited 50 us for 16 free wave slots on one CU) 152 us; edge rows + pack + exchange on a
-// high-priority stream BESIDE the interior launch: 137 us, but the interior's workgroups took the chip
-// first and the edge launch, 33 workgroups, trickled in over 73 us -- the pack ended WITH the
-// interior, the exchange hidden under nothing.
+// 140-144 us per tick at 1e6 agents.
+//
+// bench.py times the plain and the overlapped tick on the node and keeps the faster.  Forms measured and
+// dropped on the way (kernel timelines, profiles/r03_shard_timeline.txt; one GPU, nothing on the wire,
+// plain tick 124-125 us): round 2's (edge rows + pack on the model's stream, interior on a side stream,
+// exchange on a third: three cross-stream hops of 7-20 us each on the critical path, and a 1024-thread
+// pack workgroup that waited 50 us for 16 free wave slots on one CU) 152 us; edge rows + pack + exchange
+// on a high-priority stream BESIDE the interior launch: 137 us, but the interior's workgroups took the
+// chip first and the edge launch, 33 workgroups, trickled in over 73 us -- the pack ended WITH the
+// interior, the exchange hidden under nothing; the edge-first launch released through
+// hipStreamWaitValue32: 152 us (the runtime's wait is a kernel that polls without pause: place kernel
+// 26 us instead of 18.5, force kernel 103 instead of 92 while it is in flight).
 int shard_tick_split(PedoniShard* s)
 {
     PedoniModel* m = s->m;
@@ -421,7 +442,26 @@ int shard_tick_split(PedoniShard* s)
     if (m->band_hi - m->band_lo < 6 || m->force_simple) {        // band too thin to split: the plain sequence
         TRY(update_states(m));
         TRY(shard_pack(s));
+        s->n_plain += 1;
         return shard_start_next(s);
+    }
+    m->edge_flag = s->d_edge_flag;
+    m->edge_counter = s->d_edge_counter;
+    if (edge_first_ready(m)) {
+        m->edge_seq = ++s->edge_seq;
+        TRY(launch_force(m, nullptr, /*part=*/3));
+        // (only now that the launch which WILL store the word is in the queue; the waiting wave gives up
+        // after 5 s of the 100 MHz clock and raises STATUS_EDGE_WAIT)
+        hipLaunchKernelGGL(edge_wait_kernel, dim3(1), dim3(64), 0, s->comm_stream, s->d_edge_flag, s->edge_seq,
+                           m->d_live + 1, 500000000ull);
+        HIP_TRY(hipGetLastError());
+        TRY(halo_pack_from(m, s->d_send, s->cap, /*updated=*/true, s->comm_stream));
+        TRY(shard_exchange_rccl(s, s->comm_stream));
+        HIP_TRY(hipEventRecord(s->ev_recv, s->comm_stream));
+        s->in_flight = true;
+        after_update(m);
+        s->n_edge_first += 1;
+        return PEDONI_OK;
     }
     TRY(launch_force(m, nullptr, /*part=*/1));                    // edge rows (ghost rows are only NaN-marked)
     HIP_TRY(hipEventRecord(s->ev_packed, m->stream));             // fork: the edge rows are updated
@@ -434,6 +474,7 @@ int shard_tick_split(PedoniShard* s)
     HIP_TRY(hipEventRecord(s->ev_recv, s->comm_stream));
     s->in_flight = true;                                          // the next tick joins on ev_recv
     after_update(m);
+    s->n_split += 1;
     return PEDONI_OK;
 }
 
@@ -447,8 +488,10 @@ int shard_tick_rccl(PedoniShard* s)
             TRY(shard_tick_split(s));
         } else {
             TRY(pedoni_hip_halo_tick(m, shard_below(s), shard_above(s), s->d_send, s->cap));
+            s->n_plain += 1;
         }
     } else {
+        s->n_plain += 1;
         TRY(pedoni_hip_halo_unpack(m, shard_below(s), shard_above(s), s->cap));
         TRY(sort_despawn(m));
         TRY(recut_hist(s));
@@ -620,6 +663,8 @@ void pedoni_shard_destroy(PedoniShard* s)
         s->m->shard = nullptr;
     }
     if (s->comm_stream) { hipStreamSynchronize(s->comm_stream); hipStreamDestroy(s->comm_stream); }
+    if (s->m) s->m->edge_flag = s->m->edge_counter = nullptr;
+    hipFree(s->d_edge_flag);
     if (s->ev_packed) hipEventDestroy(s->ev_packed);
     if (s->ev_recv) hipEventDestroy(s->ev_recv);
     if (s->comm && rccl().CommDestroy) rccl().CommDestroy(s->comm);
@@ -723,8 +768,25 @@ int pedoni_shard_set_overlap(PedoniShard* s, int32_t on)
         HIP_TRY(hipStreamCreateWithPriority(&s->comm_stream, hipStreamNonBlocking, greatest));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_packed, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
+        // the edge-first form's signal word (PEDONI_SHARD_FORM=split keeps the two-launch form)
+        const char* form = std::getenv("PEDONI_SHARD_FORM");
+        if (!(form && std::string(form) == "split")) {
+            HIP_TRY(hipMalloc((void**)&s->d_edge_flag, 2 * sizeof(uint32_t)));
+            s->d_edge_counter = s->d_edge_flag + 1;
+            HIP_TRY(hipMemsetAsync(s->d_edge_flag, 0, 2 * sizeof(uint32_t), s->comm_stream));
+            HIP_TRY(hipStreamSynchronize(s->comm_stream));
+        }
     }
     s->overlap = on != 0;
+    return PEDONI_OK;
+}
+
+int pedoni_shard_tick_forms(PedoniShard* s, uint32_t* edge_first, uint32_t* split, uint32_t* plain)
+{
+    TRY(shard_check(s));
+    if (edge_first) *edge_first = s->n_edge_first;
+    if (split) *split = s->n_split;
+    if (plain) *plain = s->n_plain;
     return PEDONI_OK;
 }
 

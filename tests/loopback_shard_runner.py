@@ -45,7 +45,8 @@ def main():
     field = tg.oracle_field(pyoracle, sc)
     pos, dest, v0, vel = tg._lopsided_crowd(field, sc.field.size, 60_000, seed=70 + world)
 
-    single = abi.HipModel(abi.Options(), sc.field.size, field.distance_map, field.potential_maps, field.unit,
+    opts = lambda: abi.Options(math_mode=abi.MATH_FAST if os.environ.get("LOOPBACK_MATH") == "fast" else abi.MATH_EXACT)
+    single = abi.HipModel(opts(), sc.field.size, field.distance_map, field.potential_maps, field.unit,
                           sc.obstacle_array())
     single.append(pos, dest, v0, vel)
     single.sort_despawn()
@@ -65,11 +66,12 @@ def main():
     ticks = sum(k for _, k in phases)
 
     models, shards, errors, loads0 = [None] * world, [None] * world, [None] * world, [0] * world
+    forms = [None] * world
 
     def rank_main(r):
         try:
             rows_needed = abi.shard_map_rows(bounds[r], bounds[r + 1], slack, 1.4, field.unit, field.shape[0])
-            m = abi.HipModel(abi.Options(), sc.field.size, field.distance_map, field.potential_maps, field.unit,
+            m = abi.HipModel(opts(), sc.field.size, field.distance_map, field.potential_maps, field.unit,
                              sc.obstacle_array(), map_rows=rows_needed)
             models[r] = m
             s = abi.Shard(m, r, world, bounds, CAP, unique_id=uid)       # ncclCommInitRank: waits for all ranks
@@ -87,6 +89,7 @@ def main():
                 s.tick_n(k)
             s.set_overlap(False)
             m.synchronize()
+            forms[r] = s.tick_forms()
             assert loop.loopback_rccl_group_depth() == 0
         except Exception as e:                                            # noqa: BLE001
             errors[r] = f"rank {r}: {type(e).__name__}: {e}"
@@ -130,7 +133,7 @@ def main():
         "bit_equal": bool(len(got[0]) == len(want[0]) and all(bit_equal(got[k], want[k]).all() for k in (0, 2, 3))),
         "sends": int(stats[0]), "recvs": int(stats[1]), "allreduces": int(stats[2]),
         "bounds0": [int(b) for b in bounds], "bounds1": [int(b) for b in new_bounds],
-        "loads0": loads0, "loads": [s.owned_count() for s in shards],
+        "loads0": loads0, "loads": [s.owned_count() for s in shards], "forms": forms,
     }
     for s in shards:
         s.close()

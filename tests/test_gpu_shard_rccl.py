@@ -47,6 +47,27 @@ def test_rccl_driven_ticks_equal_the_single_model_bitwise(hip, world, mode):
         assert out["allreduces"] == 0 and out["bounds1"] == out["bounds0"], out
 
 
+@pytest.mark.parametrize("world,mode,env,form", [
+    (3, "overlap", {"PEDONI_FORCE_GROUP": "1"}, "edge_first"),                                       # default build, 8 slots
+    (4, "recut_overlap", {"PEDONI_FORCE_GROUP": "1", "PEDONI_FORCE_KERNEL": "s94:6"}, "edge_first"),  # the 7-wave build
+    (2, "overlap", {"PEDONI_FORCE_GROUP": "1", "PEDONI_FORCE_KERNEL": "s94:6", "LOOPBACK_MATH": "fast"}, "edge_first"),
+    (3, "overlap", {"PEDONI_FORCE_GROUP": "1", "PEDONI_SHARD_FORM": "split"}, "split"),
+    (4, "overlap", {}, "split"),                                                                      # small bands: 2-4 lanes per agent
+])
+def test_every_form_of_the_overlapped_tick_equals_the_single_model(hip, world, mode, env, form):
+    """The overlapped tick has two forms.  Edge-first: ONE force launch whose first workgroups take the
+    edge rows and release the exchange from inside the launch (a word in device memory, polled by a wave
+    on the communication stream) -- the form large bands run, forced here onto these small ones by asking
+    for the one-lane-per-agent kernels.  Split: an edge launch, then the interior launch.  Both, with 2-4
+    bands and real neighbours, bit-equal to the unsharded model; and the form asked for is the one that ran."""
+    out = _run(world, mode, env)
+    assert out["ok"], out
+    assert out["count_equal"] and out["dest_equal"] and out["bit_equal"], out
+    other = "split" if form == "edge_first" else "edge_first"
+    for f in out["forms"]:
+        assert f[form] >= 7 and f[other] == 0, out["forms"]        # (a re-cut tick is a plain one)
+
+
 def test_a_failed_send_inside_a_group_leaves_no_group_open(hip):
     """NCCL_TRY used to return from inside an open ncclGroupStart.  With the
     first ncclSend made to fail, the entry point reports it, the thread's group depth is back to

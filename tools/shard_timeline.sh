@@ -29,7 +29,8 @@ for i in range(len(ticks) - 1):
     n_force = sum(1 for r in t if name(r).startswith("force_kernel"))
     period = (int(ticks[i + 1][0]["Start_Timestamp"]) - int(t[0]["Start_Timestamp"])) / 1e3
     if period < 400:
-        forms["overlapped" if n_force >= 2 else "plain"].append((period, t))
+        edge_first = any("edge_first" in name(r) for r in t)
+        forms["overlapped (edge-first launch)" if edge_first else "overlapped" if n_force >= 2 else "plain"].append((period, t))
 for form, lst in forms.items():
     per = sorted(p for p, _ in lst)
     print(f"== {form}: {len(lst)} ticks, period median {per[len(per)//2]:.1f} us")
