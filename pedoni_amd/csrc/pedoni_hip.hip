@@ -1729,8 +1729,32 @@ uint32_t tighten_every()
 }
 } // namespace
 
+int halo_unpack_on(PedoniModel* m, const void* from_below_dev, const void* from_above_dev, uint32_t cap_each,
+                   hipStream_t on);
+
 int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const void* from_above_dev,
                            uint32_t cap_each)
+{
+    return halo_unpack_on(m, from_below_dev, from_above_dev, cap_each, nullptr);
+}
+
+// Would the next unpack re-read the live count (and pull the host's bound of the arrays back to it)?
+// Then it must not run beside the force launch of the tick before, whose surplus threads are still
+// writing DEAD keys to the slots between the live count and the OLD bound -- where the list from
+// above would land.
+bool halo_unpack_would_tighten(const PedoniModel* m, uint32_t cap_each, bool from_below, bool from_above)
+{
+    const uint32_t grow = cap_each * std::max(1u, (from_below ? 1u : 0u) + (from_above ? 1u : 0u));
+    return m->ticks_since_tighten + 1u >= tighten_every() || (uint64_t)m->n_upper + grow > m->cap;
+}
+
+// `on` = null: the model's stream.  Another stream (the shard's communication stream, right behind
+// the exchange that filled the lists): the kernel runs while the force launch of the tick before is
+// still at work -- the lists land OUTSIDE that launch's agents ([base - n, base) and behind the
+// host's bound of the stored agents), the keys they get are slots that launch does not write, and
+// the cell / row counts both add to are integer atomics.
+int halo_unpack_on(PedoniModel* m, const void* from_below_dev, const void* from_above_dev, uint32_t cap_each,
+                   hipStream_t on)
 {
     TRY(bind(m));
     if (cap_each != m->halo_cap || cap_each == 0)
@@ -1759,10 +1783,10 @@ int pedoni_hip_halo_unpack(PedoniModel* m, const void* from_below_dev, const voi
     // above its DOWN list
     const uint32_t* below = from_below_dev ? (const uint32_t*)from_below_dev + words_each : nullptr;
     const uint32_t* above = (const uint32_t*)from_above_dev;
-    Timed t(m, PEDONI_K_HALO_UNPACK);
+    Timed t(m, on ? -1 : PEDONI_K_HALO_UNPACK);      // (only launches on the model's stream are event-timed)
     if (t.rc) return t.rc;
     hipLaunchKernelGGL(halo_unpack_kernel, dim3(blocks_for(cap_each + grow, 256)), dim3(256), 0,
-                       m->stream, below, above, cap_each, grow, m->base, m->n_upper, m->d_pos[m->pv],
+                       on ? on : m->stream, below, above, cap_each, grow, m->base, m->n_upper, m->d_pos[m->pv],
                        m->d_velx[m->pv], m->d_dest[m->vd], m->d_halo, m->field, m->grid,
                        m->band_lo, m->band_hi, m->tick_parity & 1u, m->d_flags, m->d_key, m->d_scan_in,
                        m->d_row_count);

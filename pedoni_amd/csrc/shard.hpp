@@ -204,6 +204,10 @@ struct PedoniShard {
     uint32_t* d_edge_counter = nullptr;
     uint32_t edge_seq = 0;
     uint32_t n_edge_first = 0, n_split = 0, n_plain = 0;   // pedoni_shard_tick_forms
+    // inside pedoni_shard_tick_n an edge-first tick also unpacks the NEXT tick's lists, on the communication
+    // stream right behind the exchange (halo_unpack_on): the next tick then starts at its sort pass
+    bool more_ticks = false;      // not the last tick of this pedoni_shard_tick_n call
+    bool unpacked_ahead = false;  // the lists of the coming tick are in the model already
     // members of a local group (one process, one device) reach each other directly -- through the
     // caller's array, valid only inside pedoni_shard_local_group_tick_n
     PedoniShard** group = nullptr;
@@ -388,6 +392,13 @@ int shard_get_lists(PedoniShard* s)
     return shard_exchange_rccl(s, s->m->stream);
 }
 
+// the received lists into the model -- unless the tick before has done that already
+int shard_unpack(PedoniShard* s)
+{
+    if (s->unpacked_ahead) { s->unpacked_ahead = false; return PEDONI_OK; }
+    return pedoni_hip_halo_unpack(s->m, shard_below(s), shard_above(s), s->cap);
+}
+
 // overlap mode: the freshly packed lists leave on the communication stream
 int shard_start_next(PedoniShard* s)
 {
@@ -411,10 +422,14 @@ int shard_start_next(PedoniShard* s)
 // word every ~2 us (edge_wait_kernel; bounded: STATUS_EDGE_WAIT after 5 s):
 //     model stream:  unpack, sort/despawn, force(edge tiles first ... interior tiles) ........  [join]
 //     comm stream :                          [wave polls word >= seq] pack, ncclSend/Recv, [record]
-// The model's stream carries exactly the plain tick's launches minus the pack: 128 us per tick against
-// 122 plain on one GPU (bench.py's probe; the ~6 us are the join, an event wait between the force
-// launch and the next unpack), the pack done 28 us into the 86-us force launch
-// (profiles/r03_shard_timeline.txt).
+//                                                    ... [unpack of the NEXT tick's lists] [record]
+// The model's stream carries the plain tick's launches minus the pack -- and, inside pedoni_shard_tick_n,
+// minus the unpack: the lists of the coming tick are unpacked on the communication stream right behind
+// the exchange that brought them (halo_unpack_on; they land outside the agents the running force launch
+// works on), so the next tick starts at its sort pass.  121 us per tick against 122 plain on one GPU
+// (bench.py's probe, nothing on the wire; 128 with the unpack on the model's stream: what is left over
+// the unsharded tick is the reorder launch and the ~6 us of the cross-stream join), the pack done 28 us
+// into the 86-us force launch (profiles/r03_shard_timeline.txt).
 //
 // SPLIT (small bands, whose force kernel is the 2-4-lanes-per-agent one; PEDONI_SHARD_FORM=split): the
 // few rows beside the band's edges FIRST (a small launch), then the interior rows (the bulk):
@@ -437,7 +452,7 @@ int shard_start_next(PedoniShard* s)
 int shard_tick_split(PedoniShard* s)
 {
     PedoniModel* m = s->m;
-    TRY(pedoni_hip_halo_unpack(m, shard_below(s), shard_above(s), s->cap));
+    TRY(shard_unpack(s));
     TRY(sort_despawn(m));
     if (m->band_hi - m->band_lo < 6 || m->force_simple) {        // band too thin to split: the plain sequence
         TRY(update_states(m));
@@ -457,9 +472,15 @@ int shard_tick_split(PedoniShard* s)
         HIP_TRY(hipGetLastError());
         TRY(halo_pack_from(m, s->d_send, s->cap, /*updated=*/true, s->comm_stream));
         TRY(shard_exchange_rccl(s, s->comm_stream));
+        after_update(m);
+        if (s->more_ticks && !halo_unpack_would_tighten(m, s->cap, shard_below(s) != nullptr, shard_above(s) != nullptr)) {
+            // the coming tick's unpack, here and now: off the model's stream, under this tick's force launch
+            // (not the one unpack in 8 that re-reads the live count: see halo_unpack_would_tighten)
+            TRY(halo_unpack_on(m, shard_below(s), shard_above(s), s->cap, s->comm_stream));
+            s->unpacked_ahead = true;
+        }
         HIP_TRY(hipEventRecord(s->ev_recv, s->comm_stream));
         s->in_flight = true;
-        after_update(m);
         s->n_edge_first += 1;
         return PEDONI_OK;
     }
@@ -487,12 +508,15 @@ int shard_tick_rccl(PedoniShard* s)
         if (s->overlap) {
             TRY(shard_tick_split(s));
         } else {
-            TRY(pedoni_hip_halo_tick(m, shard_below(s), shard_above(s), s->d_send, s->cap));
+            TRY(shard_unpack(s));                          // (= pedoni_hip_halo_tick)
+            TRY(sort_despawn(m));
+            TRY(update_states(m));
+            TRY(shard_pack(s));
             s->n_plain += 1;
         }
     } else {
         s->n_plain += 1;
-        TRY(pedoni_hip_halo_unpack(m, shard_below(s), shard_above(s), s->cap));
+        TRY(shard_unpack(s));
         TRY(sort_despawn(m));
         TRY(recut_hist(s));
         NCCL_TRY(rccl().AllReduce(s->d_hist, s->d_hist, (size_t)m->grid.rows, ncclUint32, ncclSum, s->comm, m->stream));
@@ -688,7 +712,12 @@ int pedoni_shard_tick_n(PedoniShard* s, uint32_t steps)
     TRY(shard_check(s));
     if (!s->begun) return fail(PEDONI_E_INVALID, "shard_tick_n: call pedoni_shard_begin after loading the band");
     if (s->local_member) return fail(PEDONI_E_INVALID, "shard_tick_n: a member of a local group ticks with pedoni_shard_local_group_tick_n");
-    for (uint32_t k = 0; k < steps; ++k) TRY(shard_tick_rccl(s));
+    for (uint32_t k = 0; k < steps; ++k) {
+        s->more_ticks = k + 1 < steps;
+        const int rc = shard_tick_rccl(s);
+        s->more_ticks = false;
+        if (rc != PEDONI_OK) return rc;
+    }
     return PEDONI_OK;
 }
 
