@@ -18,6 +18,7 @@
 // atomics).
 #pragma once
 
+#include "block_order.hpp"
 #include "device_math.hpp"
 #include "pedoni_hip.h"
 
@@ -27,18 +28,6 @@ using PedoniObstacleDev = ::PedoniObstacle;
 
 constexpr uint32_t DEAD = 0xffffffffu;
 constexpr uint32_t TICKET_STRIDE = 32;   // words: one 128-byte line per XCD's ticket word (force_kernel_queue_persist)
-
-// Workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  Agents are sorted
-// by cell, so neighbouring workgroups share most of their candidate lines: map the hardware
-// block id so that every XCD works through ONE contiguous eighth of the agents (its blocks
-// b, b+8, b+16 ... become logical blocks k, k+1, k+2 ...) and neighbour rows are served by
-// the same L2.  Bijective for any grid size (cdna_hip_programming.md T1); placement is a
-// speed matter only.
-__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t n_blocks)
-{
-    const uint32_t q = n_blocks / 8u, r = n_blocks % 8u, xcd = b % 8u;
-    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
-}
 
 struct GridView {
     float unit;
@@ -1514,18 +1503,6 @@ force_kernel_queue_s94(ForceArgs a)
 // are: at agent scope it writes back the XCD's whole L2 (126 blocks per side hinted AND signalling, one
 // release per wave: force kernel 118 us).  Every launch stores the flag: with no edge agent at all,
 // workgroup 0 does.
-__device__ __forceinline__ uint32_t edge_first_tile(uint32_t b, uint32_t n_blocks, uint32_t e_lo, uint32_t e_hi, uint32_t t_hi,
-                                                    int32_t remap)
-{
-    const uint32_t n_edge = e_lo + e_hi;
-    if (b < e_lo) return b;
-    if (b < n_edge) return t_hi + (b - e_lo);
-    // the i-th tile that is neither in [0, e_lo) nor in [t_hi, t_hi + e_hi)
-    const uint32_t i = remap ? xcd_contiguous_block(b - n_edge, n_blocks - n_edge) : b - n_edge;
-    const uint32_t t = e_lo + i;
-    return t < t_hi ? t : t + e_hi;
-}
-
 struct EdgeEpilogue {       // what the workgroup's last lanes need when they leave the tile, parked in LDS before it
     const uint32_t* lo_end;   // &cell_start[edge_row[0] * cols]
     const uint32_t* hi_begin; // &cell_start[edge_row[1] * cols]

@@ -672,18 +672,13 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
             if (!m->edge_flag || !m->edge_counter) return fail(PEDONI_E_INVALID, "edge-first force launch without its signal word");
             a.edge_row[0] = lo_b; a.edge_row[1] = hi_a;
             a.edge_counter = m->edge_counter; a.edge_flag = m->edge_flag; a.edge_seq = m->edge_seq;
-            // where the edge rows should be (a hint: the kernel finds the real ones itself).  Three rows at
-            // either edge, each <= ~0.7 halo_cap agents; the live agents end about where the host's bound
-            // stood before the unpacks since its last reading of the count each added their capacity
-            const uint32_t nb = blocks_for(n, FORCE_THREADS), each = std::min(blocks_for(3u * std::max(m->halo_cap, 1u), FORCE_THREADS), nb / 2u);
+            // where the edge rows should be (block_order.hpp; a hint: the kernel finds the real ones itself).  The
+            // live agents end about where the host's bound stood before the unpacks since its last reading
+            // of the count each added their capacity
             const uint32_t lists = std::max(1u, (m->band_lo > 0 ? 1u : 0u) + (m->band_hi < rows ? 1u : 0u));
-            const uint64_t slack = (uint64_t)(m->ticks_since_tighten + 1u) * m->halo_cap * lists;
-            const uint32_t live_est = (uint32_t)(n > slack ? n - slack : 0u) + m->halo_cap / 2u;
-            const uint32_t end_tile = std::min(blocks_for(live_est, FORCE_THREADS), nb);
-            a.edge_blocks[0] = each;
-            a.edge_blocks[1] = std::min(each, nb - each);
-            a.edge_tile_hi = std::max(end_tile > a.edge_blocks[1] ? end_tile - a.edge_blocks[1] : 0u, each);
-            if (a.edge_tile_hi + a.edge_blocks[1] > nb) a.edge_tile_hi = nb - a.edge_blocks[1];
+            const EdgeHint h = edge_first_hint(n, FORCE_THREADS, m->halo_cap,
+                                               (uint64_t)(m->ticks_since_tighten + 1u) * m->halo_cap * lists);
+            a.edge_blocks[0] = h.e_lo; a.edge_blocks[1] = h.e_hi; a.edge_tile_hi = h.t_hi;
         } else if (part == 1) {
             a.seg_row[0][0] = lo_a; a.seg_row[0][1] = lo_b;
             a.seg_row[1][0] = hi_a; a.seg_row[1][1] = hi_b;

@@ -387,6 +387,18 @@ def test_rccl_group_is_closed_on_every_path(tmp_path):
     assert p.returncode == 0 and "all checks passed" in p.stdout, p.stdout + p.stderr
 
 
+def test_block_orders_are_bijections(tmp_path):
+    """pedoni_amd/csrc/block_order.hpp (tests/cpp/test_block_order.cpp): the XCD-contiguous order and the
+    edge-first order of the band's force launch give every workgroup a tile of its own for any grid size and
+    any admissible placement of the edge tiles, and the host's placement hint is always admissible."""
+    import subprocess
+    exe = tmp_path / "test_block_order"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", f"-I{ROOT / 'pedoni_amd' / 'csrc'}",
+                    "-o", str(exe), str(ROOT / "tests" / "cpp" / "test_block_order.cpp")], check=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0 and "all checks passed" in p.stdout, p.stdout[-3000:] + p.stderr
+
+
 def _in_child(code: str, **env):
     """libpedoni_hip resolves RCCL once per process: each case gets a process of its own."""
     import os
