@@ -1537,9 +1537,10 @@ struct EdgeExit {
         const uint32_t tile = ep->tile;
         const bool mine = expected ? (tile < t_lo || (tile >= t_h0 && tile < t_h1)) : ep->first_block != 0u;
         if (!mine) return;
-        __threadfence();              // release (agent scope): the workgroup's records, before it counts itself in
+        // release (agent scope): the workgroup's records are out before it counts itself in; acquire: the
+        // workgroup that completes the count has every earlier one's records behind its store of the flag
         uint32_t* counter = ep->counter;
-        if (atomicAdd(counter, 1u) + 1u == max(expected, 1u)) {
+        if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == max(expected, 1u)) {
             __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
             __hip_atomic_store(ep->flag, ep->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
