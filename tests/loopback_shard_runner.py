@@ -22,7 +22,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
-CAP = 4096
+CAP = 8192 if os.environ.get("LOOPBACK_BIG") == "1" else 4096
 
 
 def main():
@@ -41,9 +41,10 @@ def main():
     if mode == "fault":
         return fault_case(abi, pyoracle, tg, loop)
 
-    sc = tg._tall_box(70.0, 210.0)
+    big = os.environ.get("LOOPBACK_BIG") == "1"      # bands large enough for the 7-wave kernel BY SIZE
+    sc = tg._tall_box(400.0, 1000.0) if big else tg._tall_box(70.0, 210.0)
     field = tg.oracle_field(pyoracle, sc)
-    pos, dest, v0, vel = tg._lopsided_crowd(field, sc.field.size, 60_000, seed=70 + world)
+    pos, dest, v0, vel = tg._lopsided_crowd(field, sc.field.size, 1_000_000 if big else 60_000, seed=70 + world)
 
     opts = lambda: abi.Options(math_mode=abi.MATH_FAST if os.environ.get("LOOPBACK_MATH") == "fast" else abi.MATH_EXACT)
     single = abi.HipModel(opts(), sc.field.size, field.distance_map, field.potential_maps, field.unit,
@@ -63,6 +64,8 @@ def main():
                               side="right")
     phases = {"plain": [(False, 17)], "overlap": [(False, 4), (True, 9), (False, 4)],
               "recut": [(False, 17)], "recut_overlap": [(False, 3), (True, 10), (False, 4)]}[mode]
+    if big:
+        phases = [(False, 2), (True, 30), (False, 2)]
     ticks = sum(k for _, k in phases)
 
     models, shards, errors, loads0 = [None] * world, [None] * world, [None] * world, [0] * world

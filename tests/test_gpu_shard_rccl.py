@@ -53,6 +53,7 @@ def test_rccl_driven_ticks_equal_the_single_model_bitwise(hip, world, mode):
     (2, "overlap", {"PEDONI_FORCE_GROUP": "1", "PEDONI_FORCE_KERNEL": "s94:6", "LOOPBACK_MATH": "fast"}, "edge_first"),
     (3, "overlap", {"PEDONI_FORCE_GROUP": "1", "PEDONI_SHARD_FORM": "split"}, "split"),
     (4, "overlap", {}, "split"),                                                                      # small bands: 2-4 lanes per agent
+    (2, "overlap", {"LOOPBACK_BIG": "1"}, "edge_first"),              # ~5e5 agents per band: the kernel the by-size rule picks, 30 ticks
 ])
 def test_every_form_of_the_overlapped_tick_equals_the_single_model(hip, world, mode, env, form):
     """The overlapped tick has two forms.  Edge-first: ONE force launch whose first workgroups take the
