@@ -321,9 +321,30 @@ scan_apply_kernel(uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restr
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_rows_kernel(uint32_t* __restrict__ cell_count, const uint32_t* __restrict__ row_count, int32_t row0,
                  int32_t cols, uint32_t base, uint32_t* __restrict__ out, uint32_t* __restrict__ live_out,
-                 uint32_t limit, uint32_t* __restrict__ status)
+                 uint32_t limit, uint32_t* __restrict__ status, const uint32_t* __restrict__ wait_flag,
+                 uint32_t wait_seq)
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64];
+    // A band's overlapped tick: the counts of the lists unpacked on the communication stream are part of
+    // this scan's input, and this launch is not ordered behind that stream by an event (a cross-stream
+    // event wait between the force launch and this one is ~5 us of idle device; the word has long been
+    // written when this launch starts).  Every workgroup looks at the word before its first load.  Seen at
+    // the first look -- the rule -- nothing more is needed: the lists were unpacked and written back before
+    // this launch began, and its own start has dropped every stale line (an acquire at agent scope here, in
+    // 715 workgroups, drops the XCD's whole L2 each time: this kernel 10.2 us instead of 5.6).  Not yet
+    // there: wait for it (bounded like edge_wait_kernel), THEN acquire.
+    if (wait_flag) {
+        if (threadIdx.x == 0 &&
+            (int32_t)(__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wait_seq) < 0) {
+            const unsigned long long t0 = wall_clock64();
+            while ((int32_t)(__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wait_seq) < 0) {
+                if (wall_clock64() - t0 > 500000000ull) { atomicOr(status, STATUS_EDGE_WAIT); break; }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
     const int32_t row = row0 + (int32_t)blockIdx.x;
     uint32_t* in = cell_count + (size_t)row * (size_t)cols;
     uint32_t* o = out + (size_t)row * (size_t)cols;
@@ -1573,6 +1594,15 @@ __device__ __forceinline__ void force_edge_first_body(const ForceArgs& a)
 // (hipStreamWaitValue32 does work here -- tools/microbench/stream_wait_value.hip -- but the runtime
 // implements it as a kernel that polls without pause: with it in flight the place kernel took 26 us
 // instead of 18.5 and the force kernel 103 instead of 92, profiles/r03_shard_timeline.txt.)
+// ... and the word the NEXT tick's scan looks at (scan_rows_kernel's wait_flag): stored behind the unpack
+// of that tick's lists on the communication stream
+__global__ void __launch_bounds__(64) edge_post_kernel(uint32_t* flag, uint32_t seq)
+{
+    if (threadIdx.x != 0) return;
+    __threadfence();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void __launch_bounds__(64) edge_wait_kernel(const uint32_t* flag, uint32_t seq, uint32_t* status,
                                                        unsigned long long limit)
 {

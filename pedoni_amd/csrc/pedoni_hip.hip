@@ -226,6 +226,10 @@ struct PedoniModel {
     uint32_t* edge_counter = nullptr;   // device word
     uint32_t* edge_flag = nullptr;      // device word
     uint32_t edge_seq = 0;
+    // the next sort pass's first launch waits (in the kernel) for this word to reach this number: the
+    // lists unpacked on the shard's communication stream (shard.hpp); consumed by that pass
+    const uint32_t* scan_wait_flag = nullptr;
+    uint32_t scan_wait_seq = 0;
 
     // profiling
     uint32_t profile_mask = 0;
@@ -401,7 +405,8 @@ int run_row_scan(PedoniModel* m, int32_t row0, int32_t row1, uint32_t* out, uint
     if (t.rc) return t.rc;
     hipLaunchKernelGGL(scan_rows_kernel, dim3((uint32_t)(row1 - row0)), dim3(SCAN_THREADS), 0, m->stream,
                        m->d_scan_in, m->d_row_count, row0, m->grid.cols, m->base, out, m->d_live, limit,
-                       m->d_live + 1);
+                       m->d_live + 1, m->scan_wait_flag, m->scan_wait_seq);
+    m->scan_wait_flag = nullptr;
     HIP_TRY(hipGetLastError());
     return PEDONI_OK;
 }
@@ -482,6 +487,13 @@ int sort_despawn(PedoniModel* m)
         const bool key_halo = !key_all && m->halo_cap && !m->halo_keys_done;
         const bool key_appended = !key_all && n_total > m->gap_end && !m->halo_keys_done;
         if (key_all || key_halo || key_appended) {
+            if (m->scan_wait_flag) {
+                // (a pass that keys agents first: the wait cannot ride on the scan, it gets a launch of its own)
+                hipLaunchKernelGGL(edge_wait_kernel, dim3(1), dim3(64), 0, m->stream, m->scan_wait_flag, m->scan_wait_seq,
+                                   m->d_live + 1, 500000000ull);
+                m->scan_wait_flag = nullptr;
+                HIP_TRY(hipGetLastError());
+            }
             Timed t(m, PEDONI_K_BIN);
             if (t.rc) return t.rc;
             if (key_all) {

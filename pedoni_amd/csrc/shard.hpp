@@ -203,6 +203,7 @@ struct PedoniShard {
     uint32_t* d_edge_flag = nullptr;
     uint32_t* d_edge_counter = nullptr;
     uint32_t edge_seq = 0;
+    uint32_t recv_seq = 0;        // d_edge_flag[2]: the lists of tick `recv_seq` are unpacked (edge_post_kernel)
     uint32_t n_edge_first = 0, n_split = 0, n_plain = 0;   // pedoni_shard_tick_forms
     // inside pedoni_shard_tick_n an edge-first tick also unpacks the NEXT tick's lists, on the communication
     // stream right behind the exchange (halo_unpack_on): the next tick then starts at its sort pass
@@ -381,7 +382,14 @@ struct SampledProfile {
 int shard_get_lists(PedoniShard* s)
 {
     if (s->in_flight) {
-        HIP_TRY(hipStreamWaitEvent(s->m->stream, s->ev_recv, 0));
+        if (s->unpacked_ahead) {
+            // the lists are being unpacked on the communication stream: the sort pass's first launch
+            // waits for them itself (scan_rows_kernel), no event between the force launch and it
+            s->m->scan_wait_flag = s->d_edge_flag + 2;
+            s->m->scan_wait_seq = s->recv_seq;
+        } else {
+            HIP_TRY(hipStreamWaitEvent(s->m->stream, s->ev_recv, 0));
+        }
         s->in_flight = false;
         return PEDONI_OK;
     }
@@ -426,10 +434,13 @@ int shard_start_next(PedoniShard* s)
 // The model's stream carries the plain tick's launches minus the pack -- and, inside pedoni_shard_tick_n,
 // minus the unpack: the lists of the coming tick are unpacked on the communication stream right behind
 // the exchange that brought them (halo_unpack_on; they land outside the agents the running force launch
-// works on), so the next tick starts at its sort pass.  121 us per tick against 122 plain on one GPU
-// (bench.py's probe, nothing on the wire; 128 with the unpack on the model's stream: what is left over
-// the unsharded tick is the reorder launch and the ~6 us of the cross-stream join), the pack done 28 us
-// into the 86-us force launch (profiles/r03_shard_timeline.txt).
+// works on), so the next tick starts at its sort pass -- whose first launch looks at a word the
+// communication stream stores behind that unpack (edge_post_kernel, scan_rows_kernel's wait_flag) instead
+// of the model's stream waiting on an event: a cross-stream event wait between the force launch and the
+// scan was ~5 us of idle device.  The kernel timeline of the tick is then scan, place, reorder, force
+// back to back (113 us traced; 128 with unpack and event wait on the model's stream, 131 plain,
+// profiles/r03_shard_timeline.txt): what is left over the unsharded tick is the reorder launch.  The pack
+// is done 28 us into the 86-us force launch.
 //
 // SPLIT (small bands, whose force kernel is the 2-4-lanes-per-agent one; PEDONI_SHARD_FORM=split): the
 // few rows beside the band's edges FIRST (a small launch), then the interior rows (the bulk):
@@ -478,6 +489,8 @@ int shard_tick_split(PedoniShard* s)
             // (not the one unpack in 8 that re-reads the live count: see halo_unpack_would_tighten)
             TRY(halo_unpack_on(m, shard_below(s), shard_above(s), s->cap, s->comm_stream));
             s->unpacked_ahead = true;
+            hipLaunchKernelGGL(edge_post_kernel, dim3(1), dim3(64), 0, s->comm_stream, s->d_edge_flag + 2, ++s->recv_seq);
+            HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(s->ev_recv, s->comm_stream));
         s->in_flight = true;
@@ -800,9 +813,9 @@ int pedoni_shard_set_overlap(PedoniShard* s, int32_t on)
         // the edge-first form's signal word (PEDONI_SHARD_FORM=split keeps the two-launch form)
         const char* form = std::getenv("PEDONI_SHARD_FORM");
         if (!(form && std::string(form) == "split")) {
-            HIP_TRY(hipMalloc((void**)&s->d_edge_flag, 2 * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&s->d_edge_flag, 3 * sizeof(uint32_t)));     // flag, arrival counter, unpacked word
             s->d_edge_counter = s->d_edge_flag + 1;
-            HIP_TRY(hipMemsetAsync(s->d_edge_flag, 0, 2 * sizeof(uint32_t), s->comm_stream));
+            HIP_TRY(hipMemsetAsync(s->d_edge_flag, 0, 3 * sizeof(uint32_t), s->comm_stream));
             HIP_TRY(hipStreamSynchronize(s->comm_stream));
         }
     }
