@@ -65,7 +65,7 @@ def main():
     phases = {"plain": [(False, 17)], "overlap": [(False, 4), (True, 9), (False, 4)],
               "recut": [(False, 17)], "recut_overlap": [(False, 3), (True, 10), (False, 4)]}[mode]
     if big:
-        phases = [(False, 2), (True, 30), (False, 2)]
+        phases = [(False, 2), (True, int(os.environ.get("LOOPBACK_OVERLAP_TICKS", "30"))), (False, 2)]
     ticks = sum(k for _, k in phases)
 
     models, shards, errors, loads0 = [None] * world, [None] * world, [None] * world, [0] * world
