@@ -537,6 +537,7 @@ def main() -> None:
                 shard = None
                 model.close()
                 model = new_model()
+                crowd_age = 0          # (a new model: the crowd starts over)
         if shard is None:
             stage("all_gather driver", 240.0)
             runner = torch_runner(model)
