@@ -1,5 +1,4 @@
 #!/bin/bash
-#!/bin/bash
 # every BASELINE configuration at 200 steps on the round's last tree -> gpurun_out/r03_v9_bench_*.json + _all.txt
 OUT=gpurun_out
 run() { tag=$1; shift; python bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline --no-fast-leg "$@" > $OUT/r03_v9_bench_$tag.json 2> $OUT/r03_v9_bench_$tag.err; python - $tag <<'PY'
