@@ -881,7 +881,10 @@ __global__ void force_kernel_simple(ForceArgs a)
 // -- a partly filled round is cheap (idle half-waves are skipped) and the carry bookkeeping
 // costs what it saves.  Ablation of the final kernel: pairs ~95 us, field stencils ~22 us,
 // loads / fused key / integrator / stores ~28 us.
-constexpr int FORCE_THREADS = 256;
+#ifndef PEDONI_FORCE_THREADS
+#define PEDONI_FORCE_THREADS 256     // (tools/ab_repeat.sh "-DPEDONI_FORCE_THREADS=128": see profiles/r03_force_threads_ab.txt)
+#endif
+constexpr int FORCE_THREADS = PEDONI_FORCE_THREADS;
 constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 
 // TRACE (diagnostic build, PEDONI_FORCE_TRACE=1, never the product kernel): every wave adds the
