@@ -484,8 +484,10 @@ def main() -> None:
                 ok = 0
             if ok == 1:
                 # The direct path had never run with a neighbour before the driver's multi-GPU run
-                # (one GPU per development box).  So it proves itself HERE, every run: 8 ticks of it
-                # (4 plain + 4 overlapped) against 8 ticks of the torch all_gather driver on a second
+                # (one GPU per development box).  So it proves itself HERE, every run: 16 ticks of it
+                # (4 plain + 12 overlapped in one call: the edge-first launch, the lists unpacked ahead on the
+                # communication stream, and the one unpack in 8 that re-reads the live count on the model's
+                # stream all take part) against 16 ticks of the torch all_gather driver on a second
                 # model with the same crowd; every rank compares the two states bit for bit.
                 stage("verify direct exchange against all_gather", 240.0)
                 # (staged: after each stage every rank learns whether ALL ranks got through it -- a rank
@@ -496,8 +498,8 @@ def main() -> None:
                 try:
                     model.append(pos, dest, v0, vel)
                     shard.begin()
-                    shard.tick_n(4); shard.set_overlap(True); shard.tick_n(4); shard.set_overlap(False)
-                    crowd_age += 8
+                    shard.tick_n(4); shard.set_overlap(True); shard.tick_n(12); shard.set_overlap(False)
+                    crowd_age += 16
                     torch.cuda.synchronize()
                 except Exception as e:             # noqa: BLE001
                     ok, why = 0, str(e)
@@ -509,13 +511,13 @@ def main() -> None:
                     if agreed(ok):
                         try:
                             ref = torch_runner(ref_model)
-                            ref.tick_n(8)
+                            ref.tick_n(16)
                             torch.cuda.synchronize()
                             a, b = model.download(), ref_model.download()
                             same = all(x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32))
                                        for x, y in zip(a, b))
                             if not same:
-                                ok, why = 0, "direct-exchange state differs from the all_gather driver's after 8 ticks"
+                                ok, why = 0, "direct-exchange state differs from the all_gather driver's after 16 ticks"
                         except Exception as e:     # noqa: BLE001
                             ok, why = 0, str(e)
                     else:
@@ -528,7 +530,7 @@ def main() -> None:
                 verified = bool(ok)
             if ok == 1:
                 exchange = ("direct RCCL ncclSend/ncclRecv to rank+-1, driven by libpedoni_hip (pedoni_shard_tick_n); "
-                            "verified in this run: bit-equal to the all_gather driver over 8 ticks (plain + overlapped) on every rank")
+                            "verified in this run: bit-equal to the all_gather driver over 16 ticks (4 plain + 12 overlapped) on every rank")
             else:
                 print(f"[bench] rank {rank}: direct RCCL path unavailable ({why or 'another rank failed'}); "
                       "falling back to torch.distributed all_gather", file=sys.stderr)
@@ -556,7 +558,7 @@ def main() -> None:
         step_fn = shard.tick_n
         # plain tick (exchange, then the whole update) or overlapped (the next exchange under the
         # interior rows' update)?  Which is faster depends on what the exchange costs on this
-        # node: time 20 ticks of each, every rank keeps the mode that was faster for the slowest.
+        # node: time 16 ticks of each, every rank keeps the mode that was faster for the slowest.
         stage("tick-form probe", 240.0)
         mode_ms = {}
         for mode in (False, True):
@@ -564,12 +566,12 @@ def main() -> None:
             shard.tick_n(5)
             torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()   # (the library's exchanges drained before torch's collective starts)
             t0 = time.perf_counter()
-            shard.tick_n(20)
-            crowd_age += 25
+            shard.tick_n(16)
+            crowd_age += 21
             torch.cuda.synchronize()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctl)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            mode_ms[mode] = float(t.item()) / 20 * 1e3
+            mode_ms[mode] = float(t.item()) / 16 * 1e3
         use_overlap = mode_ms[True] < mode_ms[False]
         shard.set_overlap(use_overlap)
         exchange += (f"; tick form: {'overlapped' if use_overlap else 'plain'} "
