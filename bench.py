@@ -9,7 +9,7 @@ distance/potential maps at 0.25 m built by the product's own Field::from_scenari
 agents heading for the right-hand waypoint.  One "step" = one Simulator::tick of the hot
 path: sort/despawn pass (spawn_pedestrians with no new agents) + update_states.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks as a child)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  `value` is whole-job agent-steps/s with the state
@@ -113,6 +113,7 @@ def cpu_baseline(size, field, obstacles, pos, dest, v0, vel, budget_s: float = 2
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    host_cores = cores
     cores = min(cores, 32)   # a 1-GPU box's CPU share; the serial passes dominate anyway
     ofield = pyoracle.Field(field.unit, field.distance_map, field.potential_maps)
     m = pyoracle.OracleModel(size, threads=cores, use_distance_map=use_distance_map)
@@ -133,7 +134,10 @@ def cpu_baseline(size, field, obstacles, pos, dest, v0, vel, budget_s: float = 2
     t_used = time.perf_counter() - t0
     return {
         "value": agents / t_used, "unit": "agent-steps/s", "cores": cores, "kind": "port",
-        "sample": f"{steps} ticks of the same {len(pos)}-agent crowd and field "
+        # `cores` = the OpenMP threads the parallel-for really ran on; the box offers this process:
+        "host_cores_available": host_cores, "host_cores_total": os.cpu_count(),
+        "sample": f"{steps} ticks of the same {len(pos)}-agent crowd and field on {cores} of the box's "
+                  f"{host_cores} usable host cores "
                   f"({t_used:.1f} s; C port of pedoni's SocialForceModel CPU path with OpenMP where "
                   "upstream uses rayon -- the Rust binary cannot be built here)",
     }
@@ -290,6 +294,31 @@ def valu_floor(avg_launch_ms: float, workload_key: str, agents: float, kernel_sy
             "frac": floor_ms / avg_launch_ms, "clock_ghz": clock_ghz, "profile": tag, "kernel_symbol": symbol}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves.
+    This process has imported neither torch nor the HIP library and never touches the GPU; the
+    ranks run under `python -m torch.distributed.run` as a CHILD process (subprocess, never an
+    exec), on a free local port, with this command line's own arguments.  The child inherits fd 1,
+    so rank 0's ONE JSON line goes straight through; its exit code is ours.  The watchdog lives in
+    the ranks (a hung collective ends them in minutes, with the stage on stderr)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    child = subprocess.Popen(cmd, env=env)
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        return child.wait()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -314,6 +343,9 @@ def main() -> None:
 
     # the host driver of this pool only supports dmabuf IPC (RCCL / cross-process tensors)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher and nothing else
+        sys.exit(self_launch(args.gpus))
     # RCCL prints a version banner on stdout: keep fd 1 for the ONE JSON line
     json_fd = os.dup(1)
     os.dup2(2, 1)
@@ -321,9 +353,7 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
-                     "(one rank per GPU)")
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running with {world} rank(s)", file=sys.stderr)
         args.gpus = world
 
     import torch
@@ -735,10 +765,9 @@ def main() -> None:
         if G == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((width, height), field, obstacles, pos, dest, v0, vel,
                                                args.cpu_budget, args.workload != "c4seg")
-            # BASELINE.md holds no published number for this metric (the reference publishes none);
-            # the only baseline there is is the CPU port timed in this very run
-            out["vs_baseline"] = value / out["cpu_baseline"]["value"]
-            out["vs_baseline_note"] = "value / cpu_baseline.value of this run (no published reference number exists)"
+            # BASELINE.md holds no published number for this metric (the reference publishes none):
+            # vs_baseline stays null; the ratio to the CPU port timed in this very run is its own field
+            out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 

@@ -373,6 +373,28 @@ def test_bench_picks_the_newest_committed_profile():
     assert bench.valu_floor(0.05, "c3", 100_000, "force_kernel_queue_group<0, 9, 2>", 32) is None
 
 
+def test_bench_gpus_n_launches_its_own_ranks_without_a_gpu():
+    """`python bench.py --gpus 2` outside torch.distributed.run becomes a launcher: it starts the two
+    ranks as a child process (before importing torch or touching HIP) and returns the child's exit
+    code.  Without a GPU every rank refuses loudly (no CPU fallback) -- which is exactly what shows
+    here that both ranks were started and that the failure comes through."""
+    import os
+    import subprocess
+    import sys
+    if abi.device_count() > 0:
+        pytest.skip("a HIP device is visible: tests/test_gpu_bench.py runs the real 2-rank flow")
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PEDONI_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "launching 2 ranks" in p.stderr and "torch.distributed.run" in p.stderr
+    # (the first rank to refuse ends the job: the agent SIGTERMs the other, which may not get to say it too)
+    assert "bench.py needs a HIP device" in p.stderr and "local_rank: 1" in p.stderr, p.stderr[-2000:]
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
 # ---- the RCCL side of the shard driver, as far as a CPU can see it ---------------------------
 def test_rccl_group_is_closed_on_every_path(tmp_path):
     """pedoni_amd/csrc/rccl_group.hpp against a mock (tests/cpp/test_rccl_group.cpp): whatever fails
