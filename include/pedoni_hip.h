@@ -152,6 +152,14 @@ int pedoni_hip_clear(PedoniModel* m);
 int pedoni_hip_neighbor_grid_indices(PedoniModel* m, uint32_t* out, uint32_t cap,
                                      uint32_t* len);
 int pedoni_hip_neighbor_grid_shape(PedoniModel* m, uint32_t* rows, uint32_t* cols);
+/* [ext] the per-cell early-out table built at create (rows * cols words, neighbor-grid order; *len = 0
+ * when PEDONI_NO_CELL_FLAGS=1 left it out).  Bit m < 31 of word c: `get_potential(m, pos) > 0.25`
+ * (sfm.rs:69) holds for every position in the 3 x 3 cells around c, so the despawn test of an agent that
+ * starts its step in c and ends it there needs no sample; bit 31: the wall term of sfm.rs:188-192 is
+ * (+-0, +-0) for every position in c (exp(-distance / 0.2) underflows to 0, the gradient cannot vanish).
+ * Both are exact statements about the maps -- a set bit never changes a result -- and the tests check
+ * them against the oracle's samples.  Same calling convention as neighbor_grid_indices. */
+int pedoni_hip_cell_flags(PedoniModel* m, uint32_t* out, uint32_t cap, uint32_t* len);
 /* [ext] accelerations of sfm.rs:93-241 for the current sorted state (no integration) */
 int pedoni_hip_calc_accelerations(PedoniModel* m, float* acc_xy, uint32_t cap);
 

@@ -31,7 +31,7 @@ SYMBOLS = [
     "pedoni_hip_update_states", "pedoni_hip_list_pedestrians",
     "pedoni_hip_get_pedestrian_count", "pedoni_hip_append", "pedoni_hip_sort_despawn",
     "pedoni_hip_tick_n", "pedoni_hip_tick", "pedoni_hip_download", "pedoni_hip_clear",
-    "pedoni_hip_neighbor_grid_indices", "pedoni_hip_neighbor_grid_shape",
+    "pedoni_hip_neighbor_grid_indices", "pedoni_hip_neighbor_grid_shape", "pedoni_hip_cell_flags",
     "pedoni_hip_calc_accelerations", "pedoni_hip_set_stream", "pedoni_hip_get_stream",
     "pedoni_hip_synchronize", "pedoni_hip_profile", "pedoni_hip_kernel_times",
     "pedoni_hip_kernel_name", "pedoni_hip_set_band", "pedoni_hip_halo_bytes",
@@ -353,6 +353,16 @@ class HipModel:
         r, c = C.c_uint32(0), C.c_uint32(0)
         _check(self._lib, self._lib.pedoni_hip_neighbor_grid_shape(self._h, C.byref(r), C.byref(c)))
         return int(r.value), int(c.value)
+
+    def cell_flags(self) -> np.ndarray:
+        """The per-cell early-out table (include/pedoni_hip.h), shape (rows, cols); empty when left out."""
+        n = C.c_uint32(0)
+        _check(self._lib, self._lib.pedoni_hip_cell_flags(self._h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint32)
+        if n.value:
+            _check(self._lib, self._lib.pedoni_hip_cell_flags(self._h, _ptr(out, C.c_uint32), C.c_uint32(n.value), C.byref(n)))
+            return out.reshape(self.neighbor_grid_shape())
+        return out
 
     def neighbor_grid_indices(self) -> np.ndarray:
         n = C.c_uint32(0)

@@ -52,6 +52,111 @@ __device__ __forceinline__ bool survives(const FieldView& f, v2 pos, uint32_t de
     return bilinear(f.potential_maps[dest], dims_of(f), q.x, q.y) > 0.25f;
 }
 
+// ---- per-cell early-out flags (built once, at pedoni_hip_create) --------------------------------
+// Two terms of the tick cost texel gathers whose RESULT is known in advance for most agents:
+//   * the despawn test of the next pass (sfm.rs:69 `get_potential(dest, pos) > 0.25`): util::bilinear
+//     is a combination of 4 texels with non-negative weights that add up to 1 within a few ulp
+//     (util.rs:47-56; out-of-shape texels read 1e12), so it is > 0.25 for certain when every texel a
+//     position in the agent's NEXT neighbor-grid cell can touch is >= 0.26 (4 % of margin against
+//     ~1e-6 of rounding);
+//   * the wall term (sfm.rs:188-192) `direction * (2 * exp(-distance / 0.2))`: f32::exp(-d / 0.2) is
+//     exactly 0 for d > 20.8 m (its result would lie below half the smallest denormal), so the term is
+//     (+-0, +-0) whenever `direction` is finite, i.e. the Sobel gradient is finite and not (0, 0) -- and
+//     acc + (+-0) == acc bit for bit unless acc is itself +-0 (a case the kernel sends down the full path).
+// One word per neighbor-grid cell c, indexed by the cell of the agent's CURRENT position:
+//   bit m (m < 31): potential map m is >= 0.26 on every texel that util::bilinear can read for a
+//           position inside the 3 x 3 cells around c (an agent that ends its step outside that
+//           block, or with a NaN position, takes the sampled test);
+//   bit 31: on every texel the distance map's 3 x 3 Sobel taps + centre can read for a position inside
+//           c, the map lies in [21, 4096] AND steps by at least CELL_FLAG_STEP from texel to texel, with
+//           one sign, along x or along y -- then the left and right (or upper and lower) tap columns
+//           differ by >= 8 steps in exact arithmetic against < 0.02 of accumulated fp32 rounding: the
+//           gradient cannot vanish, and every tap is finite.
+// A texel outside the field reads 1e12 (util.rs:53-56): fine for the despawn bits, fatal for bit 31; a
+// texel outside the rows a band has uploaded clears both.  Everything here errs towards a cleared bit:
+// a cleared bit only means the kernel samples as before.
+constexpr uint32_t CELL_FLAG_WALL = 0x80000000u;
+constexpr uint32_t CELL_FLAG_MAPS = 31u;
+constexpr float CELL_FLAG_POTENTIAL_MIN = 0.26f;
+constexpr float CELL_FLAG_WALL_MIN = 21.0f, CELL_FLAG_WALL_MAX = 4096.0f, CELL_FLAG_STEP = 0.03f;
+
+// texel index range [lo, hi] (inclusive) that the bilinear taps of a position in grid cell `c` of width
+// `gu` can read, with one texel of slack either side for the roundings of pos / unit - 0.5 and of the
+// cell's own pos / gu (neighbor_grid.rs:27: `as i32` truncates towards zero, so cell 0 also holds (-gu, 0))
+__device__ __forceinline__ void cell_texel_range(int32_t c, double gu, double fu, int32_t apron, int32_t& lo, int32_t& hi)
+{
+    double x_lo = c == 0 ? -gu : (double)c * gu, x_hi = ((double)c + 1.0) * gu;
+    x_lo -= 1e-6 * (x_lo < 0 ? -x_lo : x_lo) + 1e-6;
+    x_hi += 1e-6 * x_hi + 1e-6;
+    const double q_lo = __builtin_floor(x_lo / fu - 0.5), q_hi = __builtin_floor(x_hi / fu - 0.5);
+    // (clamped far outside any map: the loops below only ever compare these with the map's shape)
+    lo = (int32_t)__builtin_fmax(q_lo - 1.0 - (double)apron, -1.0e9);
+    hi = (int32_t)__builtin_fmin(q_hi + 2.0 + (double)apron, 1.0e9);
+}
+
+// pass 1: the flags of each cell's OWN positions
+__global__ void cell_flags_own_kernel(FieldView f, GridView g, uint32_t* __restrict__ own)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (uint32_t)g.rows * (uint32_t)g.cols) return;
+    const int32_t cy = (int32_t)(c / (uint32_t)g.cols), cx = (int32_t)(c - (uint32_t)cy * (uint32_t)g.cols);
+    int32_t x0, x1, y0, y1;
+    cell_texel_range(cx, (double)g.unit, (double)f.unit, 0, x0, x1);
+    cell_texel_range(cy, (double)g.unit, (double)f.unit, 0, y0, y1);
+    uint32_t bits = 0;
+    // (a neighbor grid much coarser than the field: not worth a table)
+    if ((int64_t)(x1 - x0 + 3) * (int64_t)(y1 - y0 + 3) > 4096) { own[c] = 0; return; }
+    const uint32_t n_maps = f.n_maps < CELL_FLAG_MAPS ? f.n_maps : CELL_FLAG_MAPS;
+    for (uint32_t m = 0; m < n_maps; ++m) {
+        MapPtr map = as_map(f.potential_maps[m]);
+        bool ok = true;
+        for (int32_t y = y0; y <= y1 && ok; ++y) {
+            if (y < 0 || y >= f.rows) continue;                       // out of shape: reads 1e12
+            if (y < f.y_lo || y >= f.y_hi) { ok = false; break; }     // not in this band's slice
+            for (int32_t x = x0; x <= x1; ++x) {
+                if (x < 0 || x >= f.cols) continue;
+                if (!(map[(int64_t)y * f.cols + x] >= CELL_FLAG_POTENTIAL_MIN)) { ok = false; break; }   // (NaN clears)
+            }
+        }
+        if (ok) bits |= 1u << m;
+    }
+    {
+        // the Sobel taps reach one texel further each way
+        const int32_t wx0 = x0 - 1, wx1 = x1 + 1, wy0 = y0 - 1, wy1 = y1 + 1;
+        MapPtr map = as_map(f.distance_map);
+        bool ok = wx0 >= 0 && wy0 >= f.y_lo && wy0 >= 0 && wx1 < f.cols && wy1 < f.y_hi && wy1 < f.rows;
+        bool up_x = true, down_x = true, up_y = true, down_y = true;
+        for (int32_t y = wy0; ok && y <= wy1; ++y) {
+            for (int32_t x = wx0; x <= wx1; ++x) {
+                const float v = map[(int64_t)y * f.cols + x];
+                if (!(v >= CELL_FLAG_WALL_MIN && v <= CELL_FLAG_WALL_MAX)) { ok = false; break; }
+                if (x < wx1) {
+                    const float d = map[(int64_t)y * f.cols + x + 1] - v;
+                    up_x = up_x && d >= CELL_FLAG_STEP; down_x = down_x && d <= -CELL_FLAG_STEP;
+                }
+                if (y < wy1) {
+                    const float d = map[(int64_t)(y + 1) * f.cols + x] - v;
+                    up_y = up_y && d >= CELL_FLAG_STEP; down_y = down_y && d <= -CELL_FLAG_STEP;
+                }
+            }
+        }
+        if (ok && (up_x || down_x || up_y || down_y)) bits |= CELL_FLAG_WALL;
+    }
+    own[c] = bits;
+}
+
+// pass 2: a despawn bit holds for the whole 3 x 3 block the agent can end its step in
+__global__ void cell_flags_block_kernel(GridView g, const uint32_t* __restrict__ own, uint32_t* __restrict__ flags)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (uint32_t)g.rows * (uint32_t)g.cols) return;
+    const int32_t cy = (int32_t)(c / (uint32_t)g.cols), cx = (int32_t)(c - (uint32_t)cy * (uint32_t)g.cols);
+    uint32_t all = ~CELL_FLAG_WALL;
+    for (int32_t y = max(cy - 1, 0); y <= min(cy + 1, g.rows - 1); ++y)
+        for (int32_t x = max(cx - 1, 0); x <= min(cx + 1, g.cols - 1); ++x) all &= own[(int64_t)y * g.cols + x];
+    flags[c] = all | (own[c] & CELL_FLAG_WALL);
+}
+
 // ---- the sort/despawn pass (sfm.rs:58-77) on the device -----------------------------------
 // The reference bins every agent, then walks the cells row-major and each cell's list in
 // insertion order: a STABLE sort by cell id, fused with the despawn test.  Two device forms
@@ -703,6 +808,9 @@ struct ForceArgs {
     uint32_t key_end;    // stale slots [live, key_end) get DEAD keys
     SortFlags* flags;
     uint32_t parity_next;
+    // per-cell early-out flags (cell_flags_own_kernel above; null = every agent samples): bit dest = the
+    // despawn test is certain to pass anywhere in the 3 x 3 cells around, bit 31 = the wall term is +-0
+    const uint32_t* cell_flags;
     int32_t xcd_remap; // XCD-contiguous block order (PEDONI_NO_XCD_REMAP=1 turns it off)
     // edge-first form (force_kernel_queue_edge_first, a band of a sharded run): the tiles holding the agents
     // of the rows below edge_row[0] and from edge_row[1] up are worked on by the FIRST workgroups; when
@@ -721,6 +829,24 @@ struct ForceArgs {
                     // obstacle term, 4 = no pairs, 8 / 16 = phase 2 without its gather / arithmetic, 32 = no despawn sampling,
                     // 64 / 128 = no row / no counts.  The product kernels are instantiated without these switches.
 };
+
+// the early-out flags of cell (ix, iy) -- the cell of a sorted agent, which the sort pass has checked
+__device__ __forceinline__ uint32_t cell_flags_of(const ForceArgs& a, int32_t ix, int32_t iy)
+{
+    if (!a.cell_flags || (uint32_t)ix >= (uint32_t)a.grid.cols || (uint32_t)iy >= (uint32_t)a.grid.rows) return 0u;
+    return a.cell_flags[(uint32_t)iy * (uint32_t)a.grid.cols + (uint32_t)ix];
+}
+
+// sfm.rs:69 `field.get_potential(destination, pos) > 0.25` at the integrated position (= survives()).
+// `far`: the step ended outside the 3 x 3 cells around the agent's old cell, where the flags do not reach.
+__device__ __forceinline__ bool despawn_test_passes(const FieldView& f, uint32_t cflags, uint32_t dest, bool far, v2 pos)
+{
+    const bool certain = !far && dest < CELL_FLAG_MAPS && ((cflags >> dest) & 1u) != 0u && pos.x == pos.x && pos.y == pos.y;
+    if (certain) return true;
+    if (dest >= f.n_maps) return false;
+    const v2 q = field_coord(f, pos);
+    return bilinear(f.potential_maps[dest], dims_of(f), q.x, q.y) > 0.25f;
+}
 
 // goal force, sfm.rs:106-109
 template <int MODE>
@@ -1101,13 +1227,26 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
     // (the despawn test's destination and map pointer, requested here so that they travel beside the
     // wall texels instead of forming two dependent stretches of their own after the integrator)
     uint32_t dest_k = 0;
-    const float* map_k = nullptr;
-    if (a.key_next) {
-        dest_k = a.dest[id];
-        map_k = dest_k < a.field.n_maps ? a.field.potential_maps[dest_k] : nullptr;
+    if (a.key_next) dest_k = a.dest[id];
+    // The agent's cell once more, from its position (the same two divisions as in the prologue): carried
+    // round the pair loop the two coordinates are two more live VGPRs in a kernel that has none to spare
+    // (16 bytes of scratch in the 7-wave build); the asm keeps the compiler from re-using the first result.
+    {
+        float px = pos.x, py = pos.y;
+        asm volatile("" : "+v"(px), "+v"(py));
+        ix = f32_as_i32(px / a.grid.unit);
+        iy = f32_as_i32(py / a.grid.unit);
     }
+    // the early-out flags of that cell (one word, neighbouring lanes read neighbouring words)
+    const uint32_t cflags = cell_flags_of(a, ix, iy);
     if (ABL && (a.ablate & 2)) {}
-    else if (a.use_distance_map) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
+    else if (a.use_distance_map) {
+        // sfm.rs:188-192.  Flagged cell: exp(-distance / 0.2) is exactly 0 and the direction finite, the term
+        // is (+-0, +-0), and acc + (+-0) == acc bit for bit -- unless a component of acc is itself +-0 (or
+        // NaN: kept on the sampled path too), where the sign of the zero added would show.
+        const bool wall_is_zero = (cflags & CELL_FLAG_WALL) != 0u && __builtin_fabsf(acc.x) > 0.0f && __builtin_fabsf(acc.y) > 0.0f;
+        if (!wall_is_zero) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
+    }
     else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
 
     if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); tr_flush(); on_exit(); return; }
@@ -1130,12 +1269,13 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
     if (a.key_next) {
         uint32_t k = DEAD;
         int32_t cx = 0, cy = 0;
-        const v2 qk = field_coord(a.field, pos);                 // = survives(a.field, pos, dest_k)
-        if (cell_xy(a.grid, pos, cx, cy) && cy >= a.band_lo - 1 && cy <= a.band_hi &&
-            ((ABL && (a.ablate & 32)) || (map_k && bilinear(map_k, dims_of(a.field), qk.x, qk.y) > 0.25f))) {
-            {
+        if (cell_xy(a.grid, pos, cx, cy) && cy >= a.band_lo - 1 && cy <= a.band_hi) {
+            const bool far = abs(cx - ix) > 1 || abs(cy - iy) > 1;
+            // = survives(a.field, pos, dest_k): certain without a sample when the flag of the agent's map is
+            // set and the step ended inside the 3 x 3 cells the flag speaks for, at a position that is a number
+            if ((ABL && (a.ablate & 32)) || despawn_test_passes(a.field, cflags, dest_k, far, pos)) {
                 k = (uint32_t)cy * (uint32_t)a.grid.cols + (uint32_t)cx;
-                if (abs(cx - ix) > 1 || abs(cy - iy) > 1) atomicOr(&a.flags->far[a.parity_next], 1u);
+                if (far) atomicOr(&a.flags->far[a.parity_next], 1u);
             }
         }
         a.key_next[id] = k;
@@ -1395,11 +1535,8 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
         return;
     }
     uint32_t dest_k = 0;
-    const float* map_k = nullptr;
-    if (a.key_next) {
-        dest_k = a.dest[id];
-        map_k = dest_k < a.field.n_maps ? a.field.potential_maps[dest_k] : nullptr;
-    }
+    if (a.key_next) dest_k = a.dest[id];
+    const uint32_t cflags = cell_flags_of(a, ix, iy);             // (the despawn bits; the wall stencil ran beside the goal's)
     if (a.use_distance_map) acc = acc + wall;                     // (= obstacle_force_map: direction * k, lane 1's)
     else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
 
@@ -1422,11 +1559,12 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
     if (a.key_next) {
         uint32_t k = DEAD;
         int32_t cx = 0, cy = 0;
-        const v2 qk = field_coord(a.field, pos);
-        if (cell_xy(a.grid, pos, cx, cy) && cy >= a.band_lo - 1 && cy <= a.band_hi &&
-            (map_k && bilinear(map_k, dims_of(a.field), qk.x, qk.y) > 0.25f)) {
-            k = (uint32_t)cy * (uint32_t)a.grid.cols + (uint32_t)cx;
-            if (writer && (abs(cx - ix) > 1 || abs(cy - iy) > 1)) atomicOr(&a.flags->far[a.parity_next], 1u);
+        if (cell_xy(a.grid, pos, cx, cy) && cy >= a.band_lo - 1 && cy <= a.band_hi) {
+            const bool far = abs(cx - ix) > 1 || abs(cy - iy) > 1;
+            if (despawn_test_passes(a.field, cflags, dest_k, far, pos)) {
+                k = (uint32_t)cy * (uint32_t)a.grid.cols + (uint32_t)cx;
+                if (writer && far) atomicOr(&a.flags->far[a.parity_next], 1u);
+            }
         }
         if (writer) a.key_next[id] = k;
         count_key(a.cell_count, a.row_count, writer && k != DEAD, k, (uint32_t)cy);

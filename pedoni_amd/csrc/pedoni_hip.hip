@@ -173,6 +173,7 @@ struct PedoniModel {
     uint32_t* d_block_sums = nullptr;
     uint32_t block_sums_cap = 0;
     uint32_t* d_row_count = nullptr; // members per grid row (top level of the row scan)
+    uint32_t* d_cell_flags = nullptr; // per-cell early-out flags (kernels.hpp CELL_FLAG_*); null with PEDONI_NO_CELL_FLAGS=1
     uint32_t* d_tickets = nullptr;   // [8 * TICKET_STRIDE] = place_kernel's workgroups-done counter; in front of it, the
                                      // diagnostics build's 8 tile-ticket words, TICKET_STRIDE apart
     bool tickets_fresh = false;      // zeroed by the place kernel and not drawn from since
@@ -661,6 +662,7 @@ ForceArgs force_args(PedoniModel* m, float2* acc_out)
     a.key_end = m->n_upper;
     a.flags = m->d_flags;
     a.parity_next = m->tick_parity & 1u;
+    a.cell_flags = m->d_cell_flags;
     return a;
 }
 
@@ -1163,6 +1165,21 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
         C_HIP(hipMemset(m->d_row_count, 0, ((size_t)m->grid.rows + 1) * sizeof(uint32_t)));
         C_TRY(dev_alloc(&m->d_tickets, (size_t)9 * TICKET_STRIDE));     // + place_kernel's workgroups-done counter
         C_HIP(hipMemset(m->d_tickets, 0, (size_t)9 * TICKET_STRIDE * sizeof(uint32_t)));
+        // per-cell early-out flags of the despawn test and the wall term (kernels.hpp): two launches over the
+        // cells, once; PEDONI_NO_CELL_FLAGS=1 leaves them out (every agent samples: A/B runs, tests)
+        const char* ncf = std::getenv("PEDONI_NO_CELL_FLAGS");
+        if (!(ncf && ncf[0] == '1')) {
+            uint32_t* own = nullptr;
+            C_TRY(dev_alloc(&m->d_cell_flags, m->n_cells));
+            C_TRY(dev_alloc(&own, m->n_cells));
+            hipLaunchKernelGGL(cell_flags_own_kernel, dim3((m->n_cells + 255u) / 256u), dim3(256), 0, m->stream, m->field, m->grid, own);
+            hipLaunchKernelGGL(cell_flags_block_kernel, dim3((m->n_cells + 255u) / 256u), dim3(256), 0, m->stream, m->grid, own,
+                               m->d_cell_flags);
+            const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(m->stream);
+            hipFree(own);
+            C_HIP(e1);
+            C_HIP(e2);
+        }
     }
     m->band_lo = 0;
     m->band_hi = opt->use_neighbor_grid ? m->grid.rows : 0;
@@ -1199,6 +1216,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     hipFree(m->d_live); hipFree(m->d_acc); hipFree(m->d_halo);
     hipFree(m->d_spawners); hipFree(m->d_spawn_state);
     hipFree(m->d_row_count);
+    hipFree(m->d_cell_flags);
     hipFree(m->d_tickets);
     hipFree(m->d_trace);
     if (m->h_pinned) hipHostFree(m->h_pinned);
@@ -1593,6 +1611,17 @@ int pedoni_hip_neighbor_grid_shape(PedoniModel* m, uint32_t* rows, uint32_t* col
     if (!m) return fail(PEDONI_E_INVALID, "null model");
     if (rows) *rows = m->opt.use_neighbor_grid ? (uint32_t)m->grid.rows : 0;
     if (cols) *cols = m->opt.use_neighbor_grid ? (uint32_t)m->grid.cols : 0;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_cell_flags(PedoniModel* m, uint32_t* out, uint32_t cap, uint32_t* len)
+{
+    TRY(bind(m));
+    if (!len) return fail(PEDONI_E_INVALID, "cell_flags: null len");
+    *len = m->d_cell_flags ? m->n_cells : 0u;
+    if (!out || !m->d_cell_flags) return PEDONI_OK;
+    if (cap < m->n_cells) return fail(PEDONI_E_CAPACITY, "cell_flags: buffer too small");
+    HIP_TRY(hipMemcpy(out, m->d_cell_flags, (size_t)m->n_cells * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return PEDONI_OK;
 }
 

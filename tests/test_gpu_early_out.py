@@ -1,0 +1,233 @@
+"""The per-cell early-out table (kernels.hpp CELL_FLAG_*, pedoni_hip_cell_flags): a set bit is a claim about
+the field maps -- "the despawn test of sfm.rs:69 passes anywhere in these cells", "the wall term of
+sfm.rs:188-192 is (+-0, +-0) anywhere in this cell" -- and the force kernel skips the texel gathers on the
+strength of it.  Checked here three ways: every claim against the ORACLE's own samples (incl. the cells'
+edges, medial axes, cells next to a goal line); whole ticks with and without the table, bit for bit, and
+against the oracle; and that the table is not vacuous where it is meant to pay."""
+import numpy as np
+import pytest
+
+from helpers import bit_equal, box_scenario, inject_crowd, oracle_field
+from pedoni_amd import scenario as scn
+
+pytestmark = pytest.mark.gpu
+
+WALL = np.uint32(0x80000000)
+
+
+def _make_hip(hip, sc, field, **opt):
+    return hip.HipModel(hip.Options(**opt), sc.field.size, field.distance_map, field.potential_maps, field.unit,
+                        sc.obstacle_array())
+
+
+def _hall_scenario(L=260.0):
+    """A box with two inner walls (medial axes between them and the border), goal lines left and right."""
+    sc = box_scenario(L)
+    sc.obstacles += [scn.SegmentConfig(((0.35 * L, 0.2 * L), (0.35 * L, 0.55 * L)), 1.0),
+                     scn.SegmentConfig(((0.6 * L, 0.5 * L), (0.8 * L, 0.7 * L)), 2.0)]
+    return sc
+
+
+def _cell_positions(cx, cy, gu, rng, n_random=6):
+    """f32 positions that neighbor_grid.rs:27 puts into cell (cx, cy): its corners to the last ulp, its
+    edges' midpoints, random interior points."""
+    gu32 = np.float32(gu)
+    ts = np.concatenate([[0.0, 1e-7, 0.5, 1.0 - 1e-7, 1.0], rng.uniform(0, 1, n_random)])
+    xs = ((cx + ts) * gu).astype(np.float32)
+    ys = ((cy + ts) * gu).astype(np.float32)
+    # the very ends of the cell: walk to the last f32 that still truncates to the cell
+    ends_x = [np.nextafter(np.float32((cx + 1) * gu), np.float32(-np.inf)), np.float32(cx * gu),
+              np.nextafter(np.float32(cx * gu), np.float32(np.inf))]
+    ends_y = [np.nextafter(np.float32((cy + 1) * gu), np.float32(-np.inf)), np.float32(cy * gu),
+              np.nextafter(np.float32(cy * gu), np.float32(np.inf))]
+    xs = np.concatenate([xs, ends_x]).astype(np.float32)
+    ys = np.concatenate([ys, ends_y]).astype(np.float32)
+    px, py = np.meshgrid(xs, ys)
+    px, py = px.ravel(), py.ravel()
+    keep = ((px / gu32).astype(np.int32) == cx) & ((py / gu32).astype(np.int32) == cy)
+    return px[keep], py[keep]
+
+
+def _field_coord(p, unit):
+    return (p / np.float32(unit) - np.float32(0.5)).astype(np.float32)      # field.rs:236
+
+
+def test_cell_flags_never_contradict_the_oracles_samples(hip, oracle):
+    sc = _hall_scenario()
+    field = oracle_field(oracle, sc)
+    m = _make_hip(hip, sc, field)
+    flags = m.cell_flags()
+    rows, cols = m.neighbor_grid_shape()
+    m.close()
+    assert flags.shape == (rows, cols)
+    gu = 1.4
+    rng = np.random.default_rng(5)
+    n_maps = len(field.potential_maps)
+    wall = (flags & WALL) != 0
+    # the table says something: most of the hall is further than 21 m from every wall, nearly all of it
+    # further than 0.26 m from a goal line; the rows / columns along the border and the goal lines are not
+    assert 0.25 < wall.mean() < 0.9
+    for k in range(n_maps):
+        bit = (flags >> np.uint32(k)) & 1
+        assert 0.9 < bit.mean() < 1.0
+    assert not wall[0].any() and not wall[:, 0].any() and not wall[-1].any() and not wall[:, -1].any()
+
+    # ---- bit 31: the wall term is (+-0, +-0): exp(-distance / 0.2) == 0, the gradient finite and not (0, 0)
+    ys, xs = np.nonzero(wall)
+    # every flagged cell next to an unflagged one (the rim of the claim: 21 m contours, medial axes) + a sample of the rest
+    rim = np.zeros_like(wall)
+    rim[1:-1, 1:-1] = wall[1:-1, 1:-1] & ~(wall[:-2, 1:-1] & wall[2:, 1:-1] & wall[1:-1, :-2] & wall[1:-1, 2:])
+    pick = np.concatenate([np.flatnonzero(rim[ys, xs]), rng.choice(len(ys), 3000, replace=False)])
+    px, py = [], []
+    for i in pick:
+        a, b = _cell_positions(int(xs[i]), int(ys[i]), gu, rng)
+        px.append(a); py.append(b)
+    px, py = np.concatenate(px), np.concatenate(py)
+    grad, centre = oracle.sample_many(field.distance_map, _field_coord(px, field.unit), _field_coord(py, field.unit))
+    k = oracle.expf_restated((-centre / np.float32(0.2)).astype(np.float32))         # sfm.rs:191
+    assert (k == 0.0).all(), f"exp(-d / 0.2) != 0 at {np.count_nonzero(k)} of {len(k)} positions of flagged cells"
+    assert np.isfinite(grad).all()
+    assert ((grad[:, 0] != 0) | (grad[:, 1] != 0)).all(), "a flagged cell holds a position whose Sobel gradient vanishes"
+    length = np.sqrt(grad[:, 0].astype(np.float32) ** 2 + grad[:, 1].astype(np.float32) ** 2)
+    assert np.isfinite(grad / length[:, None]).all()                                   # normalize(): finite direction
+
+    # ---- bits 0..: get_potential(m, pos) > 0.25 for every position of the 3 x 3 cells around a flagged cell
+    for kmap in range(n_maps):
+        bit = ((flags >> np.uint32(kmap)) & 1).astype(bool)
+        ys, xs = np.nonzero(bit)
+        rim = np.zeros_like(bit)
+        rim[1:-1, 1:-1] = bit[1:-1, 1:-1] & ~(bit[:-2, 1:-1] & bit[2:, 1:-1] & bit[1:-1, :-2] & bit[1:-1, 2:])
+        pick = np.concatenate([np.flatnonzero(rim[ys, xs]), rng.choice(len(ys), 1500, replace=False)])
+        px, py = [], []
+        for i in pick:
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    cx, cy = int(xs[i]) + dx, int(ys[i]) + dy
+                    if 0 <= cx < cols and 0 <= cy < rows:
+                        a, b = _cell_positions(cx, cy, gu, rng, n_random=2)
+                        px.append(a); py.append(b)
+        px, py = np.concatenate(px), np.concatenate(py)
+        _, pot = oracle.sample_many(field.potential_maps[kmap], _field_coord(px, field.unit), _field_coord(py, field.unit))
+        assert (pot > 0.25).all(), f"map {kmap}: {np.count_nonzero(~(pot > 0.25))} positions fail the despawn test in flagged blocks"
+        # and the claim is not trivially everywhere: the cells on the goal line itself are unflagged
+        wp = sc.waypoint_array()[kmap]
+        gx, gy = int(wp[0] / gu), int(0.5 * (wp[1] + wp[3]) / gu)
+        assert not bit[gy, gx]
+
+
+def _crowd_with_goal_arrivals(field, size, seed):
+    """30 000 agents over the hall + 400 agents within a step of their goal line (despawn decisions on both
+    sides of 0.25, in cells whose despawn bit is clear and in their flagged neighbours)."""
+    pos, dest, v0, vel = inject_crowd(field, size, 30_000, 2, seed=seed, clearance=0.6, min_potential=0.5)
+    rng = np.random.default_rng(seed + 1)
+    L = size[0]
+    near = np.stack([L - 10.0 - rng.uniform(0.0, 1.6, 400), rng.uniform(30, L - 30, 400)], 1).astype(np.float32)
+    near_v0 = np.full(400, 1.5, np.float32)
+    near_vel = np.stack([near_v0, np.zeros(400, np.float32)], 1)
+    pos = np.concatenate([pos, near]).astype(np.float32)
+    dest = np.concatenate([dest, np.ones(400, np.uint32)])
+    v0 = np.concatenate([v0, near_v0]).astype(np.float32)
+    vel = np.concatenate([vel, near_vel]).astype(np.float32)
+    return pos, dest, v0, vel
+
+
+def test_agents_whose_acceleration_is_exactly_zero_keep_the_sampled_wall_term(hip, oracle):
+    """acc + (+-0) == acc only while acc is not itself a zero: lone agents already moving at e * v0 have
+    acc = (+0, +0) before the wall term, in cells whose wall bit is set -- the kernel must add the sampled
+    (+-0, +-0) there, as the reference does.  Bit-equal to the oracle, and the case really occurs."""
+    sc = _hall_scenario()
+    field = oracle_field(oracle, sc)
+    L = sc.field.size[0]
+    gx, gy = np.meshgrid(np.arange(0.45 * L, 0.55 * L, 6.0), np.arange(0.1 * L, 0.4 * L, 6.0))
+    pos = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32) + np.float32(0.37)
+    n = len(pos)
+    dest = np.ones(n, np.uint32)
+    v0 = np.full(n, 1.25, np.float32)
+    probe = oracle.OracleModel(sc.field.size)
+    probe.spawn_pedestrians(field, pos, dest, v0, np.zeros((n, 2), np.float32))
+    p_sorted, _, _, _ = probe.download()
+    acc0 = probe.calc_accelerations(field)                  # = e * v0 / 0.5 (+ a wall term of +-0), no neighbours in range
+    vel = (acc0 * np.float32(0.5)).astype(np.float32)        # = e * v0 exactly
+    cpu = oracle.OracleModel(sc.field.size)
+    gpu = _make_hip(hip, sc, field)
+    flags = gpu.cell_flags()
+    cell = flags[(p_sorted[:, 1] / np.float32(1.4)).astype(int), (p_sorted[:, 0] / np.float32(1.4)).astype(int)]
+    assert ((cell & WALL) != 0).mean() > 0.9
+    cpu.spawn_pedestrians(field, p_sorted, dest, v0, vel)
+    gpu.append(p_sorted, dest, v0, vel)
+    gpu.spawn_pedestrians()
+    acc = cpu.calc_accelerations(field)
+    assert (acc == 0).all(axis=1).mean() > 0.9, "the crowd was meant to have zero acceleration"
+    assert bit_equal(gpu.calc_accelerations(n), acc).all()
+    for _ in range(2):
+        cpu.update_states(field); gpu.update_states()
+        cpu.spawn_pedestrians(field); gpu.spawn_pedestrians()
+        for x, y in zip(gpu.download(), cpu.download()):
+            assert bit_equal(x, y).all() if x.dtype == np.float32 else np.array_equal(x, y)
+    gpu.close()
+
+
+@pytest.mark.parametrize("group", [None, "2"])
+def test_ticks_with_and_without_the_table_are_bit_identical(hip, oracle, monkeypatch, group):
+    """The same crowd ticked with the table, without it (PEDONI_NO_CELL_FLAGS=1) and by the oracle: all
+    state bit-equal after every tick, through despawns at the goal line; one-lane and group kernels."""
+    if group:
+        monkeypatch.setenv("PEDONI_FORCE_GROUP", group)
+    sc = _hall_scenario()
+    field = oracle_field(oracle, sc)
+    pos, dest, v0, vel = _crowd_with_goal_arrivals(field, sc.field.size, seed=11)
+    with_table = _make_hip(hip, sc, field)
+    monkeypatch.setenv("PEDONI_NO_CELL_FLAGS", "1")
+    without = _make_hip(hip, sc, field)
+    monkeypatch.delenv("PEDONI_NO_CELL_FLAGS")
+    assert with_table.cell_flags().size and not without.cell_flags().size
+    cpu = oracle.OracleModel(sc.field.size)
+    for m in (with_table, without):
+        m.append(pos, dest, v0, vel)
+        m.spawn_pedestrians()
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    n0 = cpu.get_pedestrian_count()
+
+    def same(x, y):
+        return x.shape == y.shape and (bit_equal(x, y).all() if x.dtype == np.float32 else np.array_equal(x, y))
+
+    for tick in range(6):
+        for m in (with_table, without):
+            m.update_states()
+            m.spawn_pedestrians()
+        cpu.update_states(field)
+        cpu.spawn_pedestrians(field)
+        a, b, w = with_table.download(), without.download(), cpu.download()
+        for x, y, z in zip(a, b, w):
+            assert same(x, y), f"tick {tick}: the table changes a bit"
+            assert same(x, z), f"tick {tick}: differs from the oracle"
+        assert np.array_equal(with_table.neighbor_grid_indices(), cpu.neighbor_grid_indices())
+    assert cpu.get_pedestrian_count() < n0 - 100, "the crowd near the goal line should have despawned"
+    with_table.close(); without.close()
+
+
+def test_banded_model_clears_flags_outside_its_map_rows(hip, oracle):
+    """A band that uploaded only some texel rows of the maps makes no claim about cells whose texels it does
+    not hold (they keep the sampled path, which raises the sticky status if it is ever taken there)."""
+    from pedoni_amd import abi
+    sc = _hall_scenario()
+    field = oracle_field(oracle, sc)
+    rows_total = field.distance_map.shape[0]
+    lo, hi = rows_total // 4, rows_total // 2
+    m = abi.HipModel(hip.Options(), sc.field.size, field.distance_map, field.potential_maps, field.unit,
+                     sc.obstacle_array(), map_rows=(lo, hi))
+    flags = m.cell_flags()
+    m.close()
+    full = _make_hip(hip, sc, field)
+    want = full.cell_flags()
+    full.close()
+    gu, fu = 1.4, field.unit
+    cy = np.arange(flags.shape[0])
+    # cells whose texel rows (with the stencil's apron and the 3 x 3 block) lie inside the slice keep the
+    # full model's flags; cells reaching outside are cleared
+    inside = (cy * gu / fu - 0.5 - 4 - gu / fu >= lo) & ((cy + 1) * gu / fu - 0.5 + 5 + gu / fu < hi)
+    assert inside.sum() > 20
+    assert np.array_equal(flags[inside], want[inside])
+    outside = ((cy + 1) * gu / fu + 4 < lo) | (cy * gu / fu - 4 >= hi)
+    assert outside.sum() > 20 and not flags[outside].any()
+    assert not (flags & ~want).any()          # never a claim the full model does not make
