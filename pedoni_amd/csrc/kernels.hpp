@@ -423,6 +423,17 @@ scan_apply_kernel(uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restr
 // counts are zeroed by the place kernel that follows (every workgroup here reads them).
 // Integrity: a row whose cell counts do not add up to its row count, or a live total above
 // the host's bound of the arrays, sets a sticky status bit.
+// WAIT (a band's overlapped tick): part of the counts was written by kernels of ANOTHER stream (the unpack of
+// the lists on the communication stream) that this launch is not event-ordered behind, so the counts are
+// read with agent-scope loads -- coherent whatever this XCD's L2 holds -- instead of relying on nobody
+// having pulled those lines in since the launch began.  The plain tick's scan keeps plain loads.
+template <bool WAIT> __device__ __forceinline__ uint32_t count_load(const uint32_t* p)
+{
+    if constexpr (WAIT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
+template <bool WAIT>
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_rows_kernel(uint32_t* __restrict__ cell_count, const uint32_t* __restrict__ row_count, int32_t row0,
                  int32_t cols, uint32_t base, uint32_t* __restrict__ out, uint32_t* __restrict__ live_out,
@@ -436,9 +447,12 @@ scan_rows_kernel(uint32_t* __restrict__ cell_count, const uint32_t* __restrict__
     // written when this launch starts).  Every workgroup looks at the word before its first load.  Seen at
     // the first look -- the rule -- nothing more is needed: the lists were unpacked and written back before
     // this launch began, and its own start has dropped every stale line (an acquire at agent scope here, in
-    // 715 workgroups, drops the XCD's whole L2 each time: this kernel 10.2 us instead of 5.6).  Not yet
-    // there: wait for it (bounded like edge_wait_kernel), THEN acquire.
-    if (wait_flag) {
+    // 715 workgroups, drops the XCD's whole L2 each time: this kernel 10.2 us instead of 5.6); the counts
+    // themselves are read at agent scope (count_load).  Not yet there: wait for it (bounded like
+    // edge_wait_kernel), THEN acquire.  The host rides the wait on this launch only while the launch leaves
+    // the chip room for the communication stream's kernels (run_row_scan): spinning workgroups that fill
+    // every wave slot would keep out the very launches they wait for.
+    if (WAIT && wait_flag) {
         if (threadIdx.x == 0 &&
             (int32_t)(__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wait_seq) < 0) {
             const unsigned long long t0 = wall_clock64();
@@ -459,10 +473,10 @@ scan_rows_kernel(uint32_t* __restrict__ cell_count, const uint32_t* __restrict__
     {
         const int32_t first = (int32_t)threadIdx.x * 4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = first + k < cols ? in[first + k] : 0u;
+        for (int k = 0; k < 4; ++k) v[k] = first + k < cols ? count_load<WAIT>(in + first + k) : 0u;
     }
     uint32_t part = 0;
-    for (int32_t r = row0 + (int32_t)threadIdx.x; r < row; r += SCAN_THREADS) part += row_count[r];
+    for (int32_t r = row0 + (int32_t)threadIdx.x; r < row; r += SCAN_THREADS) part += count_load<WAIT>(row_count + r);
     uint32_t before;
     block_exclusive_scan(part, lds, before);
     uint32_t carry = base + before;
@@ -471,7 +485,7 @@ scan_rows_kernel(uint32_t* __restrict__ cell_count, const uint32_t* __restrict__
         uint32_t s = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (c0 > 0) v[k] = first + k < cols ? in[first + k] : 0u;
+            if (c0 > 0) v[k] = first + k < cols ? count_load<WAIT>(in + first + k) : 0u;
             s += v[k];
         }
         uint32_t total;
@@ -487,7 +501,7 @@ scan_rows_kernel(uint32_t* __restrict__ cell_count, const uint32_t* __restrict__
         carry += total;
     }
     if (threadIdx.x == 0) {
-        if (carry - (base + before) != row_count[row]) atomicOr(status, STATUS_SCAN_MISMATCH);
+        if (carry - (base + before) != count_load<WAIT>(row_count + row)) atomicOr(status, STATUS_SCAN_MISMATCH);
         if (blockIdx.x == gridDim.x - 1) {
             o[cols] = carry;             // out[(row + 1) * cols]: the end of the last scanned row
             *live_out = carry;

@@ -231,6 +231,9 @@ struct PedoniModel {
     // lists unpacked on the shard's communication stream (shard.hpp); consumed by that pass
     const uint32_t* scan_wait_flag = nullptr;
     uint32_t scan_wait_seq = 0;
+    // ... riding on the scan's own workgroups only while their grid leaves the chip room for the other stream's
+    // launches: half of what the device holds of them at once (PEDONI_SCAN_WAIT_ROWS_MAX overrides; tests)
+    uint32_t scan_wait_rows_max = 0;
 
     // profiling
     uint32_t profile_mask = 0;
@@ -402,11 +405,26 @@ int run_scan(PedoniModel* m, uint32_t* in, uint32_t n, int zero_input, uint32_t*
 // cell counts of grid rows [row0, row1) -> cell_start (neighbor_grid_indices), one launch
 int run_row_scan(PedoniModel* m, int32_t row0, int32_t row1, uint32_t* out, uint32_t limit)
 {
+    const bool sharded_wait = m->scan_wait_flag != nullptr;
+    if (sharded_wait && (uint32_t)(row1 - row0) > m->scan_wait_rows_max) {
+        // One spinning workgroup per row would fill the chip's wave slots (a band of ~2000 rows does) and
+        // keep out the communication stream's unpack and post launches -- the very ones that store the word:
+        // stream priority does not preempt resident waves.  Such a band waits in ONE wave, ahead of the scan.
+        hipLaunchKernelGGL(edge_wait_kernel, dim3(1), dim3(64), 0, m->stream, m->scan_wait_flag, m->scan_wait_seq,
+                           m->d_live + 1, 500000000ull);
+        HIP_TRY(hipGetLastError());
+        m->scan_wait_flag = nullptr;
+    }
     Timed t(m, PEDONI_K_SCAN);
     if (t.rc) return t.rc;
-    hipLaunchKernelGGL(scan_rows_kernel, dim3((uint32_t)(row1 - row0)), dim3(SCAN_THREADS), 0, m->stream,
-                       m->d_scan_in, m->d_row_count, row0, m->grid.cols, m->base, out, m->d_live, limit,
-                       m->d_live + 1, m->scan_wait_flag, m->scan_wait_seq);
+    if (sharded_wait)
+        hipLaunchKernelGGL(scan_rows_kernel<true>, dim3((uint32_t)(row1 - row0)), dim3(SCAN_THREADS), 0, m->stream,
+                           m->d_scan_in, m->d_row_count, row0, m->grid.cols, m->base, out, m->d_live, limit,
+                           m->d_live + 1, m->scan_wait_flag, m->scan_wait_seq);
+    else
+        hipLaunchKernelGGL(scan_rows_kernel<false>, dim3((uint32_t)(row1 - row0)), dim3(SCAN_THREADS), 0, m->stream,
+                           m->d_scan_in, m->d_row_count, row0, m->grid.cols, m->base, out, m->d_live, limit,
+                           m->d_live + 1, (const uint32_t*)nullptr, 0u);
     m->scan_wait_flag = nullptr;
     HIP_TRY(hipGetLastError());
     return PEDONI_OK;
@@ -1181,6 +1199,13 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
             C_HIP(e2);
         }
     }
+    {
+        int per_cu = 0, cus = 0;
+        C_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_rows_kernel<true>, SCAN_THREADS, 0));
+        C_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        m->scan_wait_rows_max = (uint32_t)std::max(0, per_cu * cus / 2);
+        if (const char* sw = std::getenv("PEDONI_SCAN_WAIT_ROWS_MAX")) m->scan_wait_rows_max = (uint32_t)std::atoi(sw);
+    }
     m->band_lo = 0;
     m->band_hi = opt->use_neighbor_grid ? m->grid.rows : 0;
 
@@ -1348,25 +1373,60 @@ bool graph_matches(const PedoniModel* m, const PedoniModel::TickGraph& g)
            g.cs == m->cs && g.sk == m->sk && g.stream == m->stream;
 }
 
+// the host bookkeeping a tick advances (sort_despawn, update_states): a capture runs it without running
+// anything on the device, so a capture that fails midway must put it back
+struct HostBook {
+    int pv, vd, cs, sk;
+    uint32_t tick_parity, n_upper, gap_end, ticks_since_tighten;
+    bool have_old, keys_valid, counts_dirty, sorted, halo_keys_done, tickets_fresh;
+    static HostBook of(const PedoniModel* m)
+    {
+        return HostBook{m->pv, m->vd, m->cs, m->sk, m->tick_parity, m->n_upper, m->gap_end, m->ticks_since_tighten,
+                        m->have_old, m->keys_valid, m->counts_dirty, m->sorted, m->halo_keys_done, m->tickets_fresh};
+    }
+    void restore(PedoniModel* m) const
+    {
+        m->pv = pv; m->vd = vd; m->cs = cs; m->sk = sk; m->tick_parity = tick_parity; m->n_upper = n_upper;
+        m->gap_end = gap_end; m->ticks_since_tighten = ticks_since_tighten; m->have_old = have_old;
+        m->keys_valid = keys_valid; m->counts_dirty = counts_dirty; m->sorted = sorted;
+        m->halo_keys_done = halo_keys_done; m->tickets_fresh = tickets_fresh;
+    }
+};
+
 int tick_graph_pair(PedoniModel* m)
 {
     const uint32_t parity = m->tick_parity & 1u;
     PedoniModel::TickGraph& g = m->graphs[parity];
     if (!graph_matches(m, g)) {
-        if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-        g.valid = false;
-        TRY(capture_ticks(m, 2, &g));
-        // the pair that starts one tick later, while we are at it: a caller that mixes single ticks
-        // in (every n-th tick event-timed) then never meets a capture + instantiate in mid-run
-        PedoniModel::TickGraph& o = m->graphs[parity ^ 1u];
-        if (!(o.valid && o.exec && o.n_upper == m->n_upper && o.base == m->base && o.stream == m->stream)) {
-            if (o.exec) { hipGraphExecDestroy(o.exec); o.exec = nullptr; }
-            o.valid = false;
-            TRY(capture_ticks(m, 1, nullptr));
-            TRY(capture_ticks(m, 2, &o));
-            TRY(capture_ticks(m, 1, nullptr));
-            if ((m->tick_parity & 1u) != parity || !graph_matches(m, g))
-                return fail(PEDONI_E_HIP, "tick graph: host state did not return after the second capture");
+        // Up to four captures follow (this pair; one discarded tick, the other pair, one discarded tick), each
+        // advancing the host bookkeeping by what it records.  If any of them fails, nothing has run on the
+        // device: the bookkeeping goes back to where it stood, the graphs are dropped and this model ticks
+        // eagerly from now on (it used to return with the host up to three ticks ahead of the device).
+        const HostBook before = HostBook::of(m);
+        auto captured = [&]() -> int {
+            if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+            g.valid = false;
+            TRY(capture_ticks(m, 2, &g));
+            // the pair that starts one tick later, while we are at it: a caller that mixes single ticks
+            // in (every n-th tick event-timed) then never meets a capture + instantiate in mid-run
+            PedoniModel::TickGraph& o = m->graphs[parity ^ 1u];
+            if (!(o.valid && o.exec && o.n_upper == m->n_upper && o.base == m->base && o.stream == m->stream)) {
+                if (o.exec) { hipGraphExecDestroy(o.exec); o.exec = nullptr; }
+                o.valid = false;
+                TRY(capture_ticks(m, 1, nullptr));
+                TRY(capture_ticks(m, 2, &o));
+                TRY(capture_ticks(m, 1, nullptr));
+                if ((m->tick_parity & 1u) != parity || !graph_matches(m, g))
+                    return fail(PEDONI_E_HIP, "tick graph: host state did not return after the second capture");
+            }
+            return PEDONI_OK;
+        };
+        const int rc = captured();
+        if (rc != PEDONI_OK) {
+            before.restore(m);
+            m->drop_graphs();
+            m->use_graph = false;
+            return rc;
         }
     }
     {

@@ -512,7 +512,32 @@ int shard_tick_split(PedoniShard* s)
     return PEDONI_OK;
 }
 
+// A tick that failed midway leaves the shard's hand-offs (lists in flight, lists unpacked ahead, the band's
+// arrays half updated) in no state a further tick could continue from: settle what is under way and refuse
+// further ticks until the caller reloads the band and calls pedoni_shard_begin again.
+void shard_poison(PedoniShard* s)
+{
+    if (s->comm_stream) hipStreamSynchronize(s->comm_stream);
+    if (s->m && s->m->stream) hipStreamSynchronize(s->m->stream);
+    s->in_flight = s->unpacked_ahead = s->more_ticks = s->lists_ready = false;
+    if (s->m) s->m->scan_wait_flag = nullptr;
+    s->begun = false;
+}
+
+int shard_tick_rccl_body(PedoniShard* s);
 int shard_tick_rccl(PedoniShard* s)
+{
+    // (keep the failing call's message: the settling below makes HIP calls of its own)
+    const int rc = shard_tick_rccl_body(s);
+    if (rc != PEDONI_OK) {
+        const std::string why = g_last_error;
+        shard_poison(s);
+        g_last_error = why + " (the shard is stopped: reload the band and call pedoni_shard_begin)";
+    }
+    return rc;
+}
+
+int shard_tick_rccl_body(PedoniShard* s)
 {
     PedoniModel* m = s->m;
     SampledProfile sampled(m);
@@ -553,8 +578,18 @@ int shard_tick_rccl(PedoniShard* s)
 
 void shard_detach_model(PedoniModel* m)
 {
-    if (m->shard) m->shard->m = nullptr;
+    if (PedoniShard* s = m->shard) {
+        // the communication stream may still hold the last overlapped tick's edge wait, pack and send, which
+        // read the model's arrays: drained HERE, before the caller frees them (not left to hipFree's implicit
+        // device synchronisation)
+        if (s->comm_stream) hipStreamSynchronize(s->comm_stream);
+        s->in_flight = s->unpacked_ahead = s->more_ticks = false;
+        s->begun = false;
+        s->m = nullptr;
+    }
     m->shard = nullptr;
+    m->edge_flag = m->edge_counter = nullptr;
+    m->scan_wait_flag = nullptr;
 }
 
 extern "C" {

@@ -30,6 +30,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -105,6 +106,13 @@ ncclResult_t do_recv(const Op& o)
     }
     if (m.bytes != o.bytes) return ncclInvalidArgument;       // size mismatch between the two ends
     if (hipStreamWaitEvent(o.st, m.ready, 0) != hipSuccess) return ncclUnhandledCudaError;
+    // LOOPBACK_RCCL_RECV_DELAY_US: a straggling neighbour -- the message reaches the receiver's stream this
+    // much later (a host function in stream order: everything behind it on that stream waits)
+    static const long delay_us = [] { const char* d = std::getenv("LOOPBACK_RCCL_RECV_DELAY_US"); return d ? std::atol(d) : 0L; }();
+    if (delay_us > 0 && o.bytes > 64 &&
+        hipLaunchHostFunc(o.st, [](void* us) { std::this_thread::sleep_for(std::chrono::microseconds((long)(intptr_t)us)); },
+                          (void*)(intptr_t)delay_us) != hipSuccess)
+        return ncclUnhandledCudaError;
     if (o.bytes && hipMemcpyAsync(o.dst, m.staging, o.bytes, hipMemcpyDeviceToDevice, o.st) != hipSuccess)
         return ncclUnhandledCudaError;
     g_stat_recv++;

@@ -42,7 +42,8 @@ def main():
         return fault_case(abi, pyoracle, tg, loop)
 
     big = os.environ.get("LOOPBACK_BIG") == "1"      # bands large enough for the 7-wave kernel BY SIZE
-    sc = tg._tall_box(400.0, 1000.0) if big else tg._tall_box(70.0, 210.0)
+    tall = os.environ.get("LOOPBACK_TALL") == "1"    # bands of > 2048 grid rows each (a narrow, very tall box)
+    sc = tg._tall_box(400.0, 1000.0) if big else (tg._tall_box(24.0, 3100.0 * world) if tall else tg._tall_box(70.0, 210.0))
     field = tg.oracle_field(pyoracle, sc)
     pos, dest, v0, vel = tg._lopsided_crowd(field, sc.field.size, 1_000_000 if big else 60_000, seed=70 + world)
 
@@ -136,7 +137,7 @@ def main():
         "bit_equal": bool(len(got[0]) == len(want[0]) and all(bit_equal(got[k], want[k]).all() for k in (0, 2, 3))),
         "sends": int(stats[0]), "recvs": int(stats[1]), "allreduces": int(stats[2]),
         "bounds0": [int(b) for b in bounds], "bounds1": [int(b) for b in new_bounds],
-        "loads0": loads0, "loads": [s.owned_count() for s in shards], "forms": forms,
+        "loads0": loads0, "loads": [s.owned_count() for s in shards], "forms": forms, "grid_rows": int(rows),
     }
     for s in shards:
         s.close()

@@ -69,6 +69,29 @@ def test_every_form_of_the_overlapped_tick_equals_the_single_model(hip, world, m
         assert f[form] >= 7 and f[other] == 0, out["forms"]        # (a re-cut tick is a plain one)
 
 
+@pytest.mark.parametrize("world,env,min_rows", [
+    # a straggling neighbour: every list reaches the receiver's communication stream 400 us late, i.e. WHILE the
+    # next tick's scan is already spinning on the "lists unpacked" word (the riding wait's slow path)
+    (3, {"PEDONI_FORCE_GROUP": "1", "LOOPBACK_RCCL_RECV_DELAY_US": "400"}, 0),
+    # the same with the wait taken out of the scan's workgroups into one wave ahead of it (what a band of more
+    # rows than half the chip's resident workgroups gets: run_row_scan)
+    (3, {"PEDONI_FORCE_GROUP": "1", "LOOPBACK_RCCL_RECV_DELAY_US": "400", "PEDONI_SCAN_WAIT_ROWS_MAX": "0"}, 0),
+    # bands of MORE grid rows than the chip holds scan workgroups (2048), late lists: one
+    # spinning workgroup per row would take every wave slot and keep out the unpack that stores the word
+    (2, {"PEDONI_FORCE_GROUP": "1", "LOOPBACK_RCCL_RECV_DELAY_US": "400", "LOOPBACK_TALL": "1"}, 4400),
+])
+def test_overlapped_tick_with_late_lists_and_bands_taller_than_the_chip(hip, world, env, min_rows):
+    out = _run(world, "overlap", env)
+    assert out["ok"], out
+    assert out["count_equal"] and out["dest_equal"] and out["bit_equal"], out
+    assert out["grid_rows"] >= min_rows
+    if min_rows:
+        rows = [b - a for a, b in zip(out["bounds0"], out["bounds0"][1:])]
+        assert max(rows) > 2048, rows
+    for f in out["forms"]:
+        assert f["edge_first"] >= 7, out["forms"]
+
+
 def test_a_failed_send_inside_a_group_leaves_no_group_open(hip):
     """NCCL_TRY used to return from inside an open ncclGroupStart.  With the
     first ncclSend made to fail, the entry point reports it, the thread's group depth is back to
