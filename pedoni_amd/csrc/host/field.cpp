@@ -63,7 +63,8 @@ inline float float_of(uint32_t u)
 // left-to-right walk in which each step either enters the next pixel column on the same
 // scanline or moves to the scanline boundary (1e-9 nudge).  Differs from an exact grid
 // traversal only where a segment passes through a pixel corner or ends on a pixel edge
-// (19 of ~250 000 burnt cells over the reference's 14 scenario files;
+// (over the reference's 14 scenario files + the 3 fixtures: 3 distinct cells of the obstacle masks and
+// 16 cells of waypoint outlines, of ~250 000 burnt cells -- listed in tests/golden/burner_corner_ties.json;
 // tests/test_host_cpu.py::test_line_burner_is_all_touched_up_to_corner_ties).
 struct Burner {
     uint8_t* mask;

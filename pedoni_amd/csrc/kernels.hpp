@@ -29,6 +29,19 @@ using PedoniObstacleDev = ::PedoniObstacle;
 constexpr uint32_t DEAD = 0xffffffffu;
 constexpr uint32_t TICKET_STRIDE = 32;   // words: one 128-byte line per XCD's ticket word (force_kernel_queue_persist)
 
+// Diagnostics hooks.  The tile functions of the force kernel and the body of the place kernel take a policy
+// object: the product kernels are instantiated with NoDiag -- every hook an empty inline, every switch a
+// constant false, nothing of it in their code -- and csrc/kernels_diag.hpp (diagnostics build only) has the
+// ones that time a wave's phases or switch parts of a kernel off for ablation runs.
+struct ForceArgs;
+struct NoDiag {
+    __device__ __forceinline__ NoDiag() {}
+    __device__ __forceinline__ NoDiag(const ForceArgs&, uint32_t /*wave record*/) {}
+    __device__ __forceinline__ void lap(int /*phase*/) {}          // the phase that just ended
+    __device__ __forceinline__ void flush() {}                     // the wave's lanes leave the tile
+    __device__ __forceinline__ constexpr bool off(uint32_t /*part*/) const { return false; }
+};
+
 struct GridView {
     float unit;
     int32_t rows, cols; // NeighborGrid.shape = (rows, cols) (neighbor_grid.rs:14-20)
@@ -547,19 +560,8 @@ __device__ __forceinline__ void reorder_body(const uint32_t* __restrict__ key, u
 //    rows start beyond j and are skipped, so on average half of the 3 x 3 block is read.
 //  general form: a provisional slot by a second round of atomics on the (zeroed) counter;
 //    K_REORDER puts the cell in order and zeroes the counter again.
-#ifdef PEDONI_DIAGNOSTICS
-__global__ void probe_empty_kernel(uint32_t* p, uint32_t n) { if (n == 0xffffffffu) p[0] = 1; }   // (dispatch-cost probe)
-#endif
-#ifdef PEDONI_DIAGNOSTICS
-// diagnostics: parts of place_kernel switched off for timed launches (tools/ablate_place.py, place_probe.py; the
-// pass's results are wrong): 1 = no rank scan, 2 = no record move, 4 = no old-range loads, 8 = hardware workgroup
-// order, 16 = return at once, 32 = key load + one store only, 64 = the bare record move.  (The switch is a kernel
-// argument: a __device__ variable set with hipMemcpyToSymbol never reached the kernel's scalar loads.)
-#define PLACE_ABLATE(bit) (dbg & (bit))
-#else
-#define PLACE_ABLATE(bit) 0
-#endif
 
+template <class DIAG>
 __device__ __forceinline__ void place_body(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
                              GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
                              const uint32_t* __restrict__ cs_new, SortFlags* __restrict__ flags,
@@ -567,10 +569,9 @@ __device__ __forceinline__ void place_body(const uint32_t* __restrict__ key, uin
                              uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed,
                              uint32_t* __restrict__ row_count, int32_t row0, int32_t row1,
                              uint32_t* __restrict__ status, uint32_t* __restrict__ tickets,
-                             uint32_t* __restrict__ done_count, uint32_t dbg)
+                             uint32_t* __restrict__ done_count, const DIAG diag)
 {
-    (void)dbg;
-    if (PLACE_ABLATE(128)) return;                   // (diagnostics: before anything is read but the arguments)
+    if (diag.off(128)) return;                       // (diagnostics: before anything is read but the arguments)
     // `done_count` != null: the host launches NO reorder kernel after this pass (steady state:
     // nothing appended, not a band) and a general-form pass that only the device knows of -- an agent
     // that moved more than one cell -- is put in order here, by the workgroup that finishes last:
@@ -578,7 +579,7 @@ __device__ __forceinline__ void place_body(const uint32_t* __restrict__ key, uin
     // counts last acquires and ranks every cell alone.  Slow and correct, for a case that a finite
     // state cannot reach (|v| dt <= 0.38 m < one cell); the common tick reads one flag and pays nothing.
     const bool collect = done_count != nullptr && flags->far[parity] != 0;
-    uint32_t j = i0 + (PLACE_ABLATE(8) ? blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
+    uint32_t j = i0 + (diag.off(8) ? blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
     // the NEXT tick's flag is raised by this tick's update_states and the next K_KEY; it can
     // be cleared here because every key of this tick has been written and nothing reads it now
     if (blockIdx.x == 0) {
@@ -593,12 +594,12 @@ __device__ __forceinline__ void place_body(const uint32_t* __restrict__ key, uin
         // (diagnostics build: the tile tickets of the persistent force kernel that follows this pass)
         if (tickets && threadIdx.x < 8u) tickets[threadIdx.x * TICKET_STRIDE] = 0;
     }
-    if (PLACE_ABLATE(16)) return;                    // (diagnostics: the launch alone)
-    if (PLACE_ABLATE(32)) {                          // (diagnostics: key load + packed-cell store only)
+    if (diag.off(16)) return;                    // (diagnostics: the launch alone)
+    if (diag.off(32)) {                          // (diagnostics: key load + packed-cell store only)
         if (j < n_total) a.skey_out[j] = key[j];
         return;
     }
-    if (PLACE_ABLATE(64)) {                          // (diagnostics: the bare record move at j)
+    if (diag.off(64)) {                          // (diagnostics: the bare record move at j)
         if (j < n_total && key[j] != DEAD) {
             a.pos_out[j] = a.pos_in[j]; a.velx_out[j] = a.velx_in[j]; a.dest_out[j] = a.dest_in[j]; a.skey_out[j] = key[j];
         }
@@ -621,19 +622,19 @@ __device__ __forceinline__ void place_body(const uint32_t* __restrict__ key, uin
         const uint32_t d_in = a.dest_in[j];
         const uint32_t start = cs_new[c];
         CellRanges r{};
-        if (!PLACE_ABLATE(4)) r = old_ranges(cs_old, grid, (int32_t)cx, (int32_t)cy);
+        if (!diag.off(4)) r = old_ranges(cs_old, grid, (int32_t)cx, (int32_t)cy);
         uint32_t before = 0;
-        if (!PLACE_ABLATE(1)) {
+        if (!diag.off(1)) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const uint32_t hi = min(r.hi[k], j);
                 for (uint32_t i = r.lo[k]; i < hi; ++i) before += key[i] == c ? 1u : 0u;
             }
         }
-        const uint32_t to = PLACE_ABLATE(1) ? j : start + before;
+        const uint32_t to = diag.off(1) ? j : start + before;
         // (`to >= n_total` is never taken unless the live count exceeds the host's bound:
         // scan_rows_kernel has raised STATUS_LIVE_OVERFLOW then; do not write past the arrays)
-        if (PLACE_ABLATE(2)) {
+        if (diag.off(2)) {
             if (to < n_total) a.skey_out[to] = pack_cell(cx, cy) + (uint32_t)(p_in.x + v_in.x) + d_in;
         } else if (to < n_total) {                               // = move_agent(a, j, to, ..)
             a.pos_out[to] = p_in;
@@ -673,58 +674,10 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
                              uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed,
                              uint32_t* __restrict__ row_count, int32_t row0, int32_t row1,
                              uint32_t* __restrict__ status, uint32_t* __restrict__ tickets,
-                             uint32_t* __restrict__ done_count, uint32_t dbg)
+                             uint32_t* __restrict__ done_count)
 {
-    place_body(key, i0, n_total, grid, band, cs_old, cs_new, flags, parity, cell_count, a, slots, halo_consumed, row_count, row0, row1, status, tickets, done_count, dbg);
+    place_body(key, i0, n_total, grid, band, cs_old, cs_new, flags, parity, cell_count, a, slots, halo_consumed, row_count, row0, row1, status, tickets, done_count, NoDiag{});
 }
-
-#ifdef PEDONI_DIAGNOSTICS
-// (dispatch-cost probe: the same body under another name, so that a profile tells the probe launch from the real one)
-__global__ void place_kernel_probe(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
-                             GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
-                             const uint32_t* __restrict__ cs_new, SortFlags* __restrict__ flags,
-                             uint32_t parity, uint32_t* __restrict__ cell_count, SoA a,
-                             uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed,
-                             uint32_t* __restrict__ row_count, int32_t row0, int32_t row1,
-                             uint32_t* __restrict__ status, uint32_t* __restrict__ tickets,
-                             uint32_t* __restrict__ done_count, uint32_t dbg)
-{
-    place_body(key, i0, n_total, grid, band, cs_old, cs_new, flags, parity, cell_count, a, slots, halo_consumed, row_count, row0, row1, status, tickets, done_count, dbg);
-}
-#endif
-
-#ifdef PEDONI_DIAGNOSTICS
-// dispatch-cost probe: place_kernel's exact signature, an empty body (not one argument is read)
-__global__ void place_signature_only(const uint32_t* __restrict__, uint32_t, uint32_t, GridView, BandView, const uint32_t* __restrict__,
-                                     const uint32_t* __restrict__, SortFlags* __restrict__, uint32_t, uint32_t* __restrict__, SoA,
-                                     uint32_t* __restrict__, HaloIn* __restrict__, uint32_t* __restrict__, int32_t, int32_t,
-                                     uint32_t* __restrict__, uint32_t* __restrict__, uint32_t* __restrict__, uint32_t)
-{
-}
-#endif
-
-#ifdef PEDONI_DIAGNOSTICS
-// dispatch-cost probes, continued: the same signature reading ONE argument (the last) / ALL of them, then leaving
-__global__ void place_reads_one(const uint32_t* __restrict__, uint32_t, uint32_t, GridView, BandView, const uint32_t* __restrict__,
-                                const uint32_t* __restrict__, SortFlags* __restrict__, uint32_t, uint32_t* __restrict__ out, SoA,
-                                uint32_t* __restrict__, HaloIn* __restrict__, uint32_t* __restrict__, int32_t, int32_t,
-                                uint32_t* __restrict__, uint32_t* __restrict__, uint32_t* __restrict__, uint32_t dbg)
-{
-    if (dbg == 0x12345678u) out[0] = 1;
-}
-__global__ void place_reads_all(const uint32_t* __restrict__ a0, uint32_t a1, uint32_t a2, GridView g, BandView b, const uint32_t* __restrict__ a3,
-                                const uint32_t* __restrict__ a4, SortFlags* __restrict__ a5, uint32_t a6, uint32_t* __restrict__ out, SoA s,
-                                uint32_t* __restrict__ a7, HaloIn* __restrict__ a8, uint32_t* __restrict__ a9, int32_t a10, int32_t a11,
-                                uint32_t* __restrict__ a12, uint32_t* __restrict__ a13, uint32_t* __restrict__ a14, uint32_t dbg)
-{
-    unsigned long long sum = (unsigned long long)a0 + a1 + a2 + (unsigned long long)g.rows + g.cols + b.lo + b.hi + b.sharded + (unsigned long long)a3 +
-        (unsigned long long)a4 + (unsigned long long)a5 + a6 + (unsigned long long)s.pos_in + (unsigned long long)s.velx_in + (unsigned long long)s.dest_in +
-        (unsigned long long)s.pos_out + (unsigned long long)s.velx_out + (unsigned long long)s.dest_out + (unsigned long long)s.skey_out + s.fast +
-        (unsigned long long)a7 + (unsigned long long)a8 + (unsigned long long)a9 + a10 + a11 + (unsigned long long)a12 + (unsigned long long)a13 +
-        (unsigned long long)a14 + dbg;
-    if (sum == 0x1234567812345678ull) out[0] = 1;
-}
-#endif
 
 // ---- K_REORDER (general form only) --------------------------------------------------------
 // sfm.rs:66-75: an agent's place inside its cell is the number of cell-mates with a smaller
@@ -838,10 +791,8 @@ struct ForceArgs {
     uint32_t edge_seq;
     uint32_t* tickets;  // persistent form: 8 ticket words, TICKET_STRIDE apart (zeroed by the place kernel)
     uint32_t n_tiles;   // persistent form: 64-agent tiles of this launch
-    unsigned long long* trace; // TRACE build only (7 words, see force_queue_body)
-    int32_t ablate; // PEDONI_DIAGNOSTICS builds only (force_kernel_queue_ablate, PEDONI_ABLATE): 1 = no goal sampling, 2 = no
-                    // obstacle term, 4 = no pairs, 8 / 16 = phase 2 without its gather / arithmetic, 32 = no despawn sampling,
-                    // 64 / 128 = no row / no counts.  The product kernels are instantiated without these switches.
+    unsigned long long* trace; // diagnostics build only: per-wave records of TraceDiag (kernels_diag.hpp)
+    int32_t ablate;            // diagnostics build only: SwitchDiag's bits (kernels_diag.hpp); no product kernel reads it
 };
 
 // the early-out flags of cell (ix, iy) -- the cell of a sorted agent, which the sort pass has checked
@@ -1027,10 +978,6 @@ __global__ void force_kernel_simple(ForceArgs a)
 constexpr int FORCE_THREADS = PEDONI_FORCE_THREADS;
 constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 
-// TRACE (diagnostic build, PEDONI_FORCE_TRACE=1, never the product kernel): every wave adds the
-// shader cycles (s_memtime) it spent in the prologue, in phases 1 / 2 / 3 and in the epilogue to
-// its own record a.trace[8 * wave + 0..4], its lifetime to [5] and 1 to [6] -- where a wave's
-// WALL time goes, waiting and being passed over by the arbiter included.
 // One tile = the 64 agents of one wave: sorted indices base + 64 * tile + lane.  `queue` / `who` are
 // the calling wave's own LDS queue, `tab` the block's copy of the exp table.
 // EXIT: called by every lane exactly once, where it leaves the tile (the lanes of a wave leave at up to four
@@ -1038,32 +985,12 @@ constexpr int FORCE_WAVES = FORCE_THREADS / 64;
 // would be two more SGPRs held across the whole tile, which at the 7-wave budget spills).  The default does nothing.
 struct NoExit { __device__ __forceinline__ void operator()() const {} };
 
-template <int MODE, int SLOTS, bool TRACE = false, bool ABL = false, class EXIT = NoExit>
+template <int MODE, int SLOTS, class DIAG = NoDiag, class EXIT = NoExit>
 __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint32_t t0, float2* __restrict__ queue,
                                                  uint32_t* __restrict__ who, const uint64_t* __restrict__ tab,
                                                  const EXIT on_exit = EXIT{})
 {
-    unsigned long long tr_t0 = 0, tr_mark = 0, tr_acc[5] = {0, 0, 0, 0, 0};
-    auto tr_lap = [&](int which) {
-        if constexpr (TRACE) {
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            tr_acc[which] += now - tr_mark;
-            tr_mark = now;
-        }
-    };
-    auto tr_flush = [&]() {
-        if constexpr (TRACE) {
-            if ((threadIdx.x & 63u) == 0 && a.trace) {
-                tr_lap(4);
-                // one 64-byte record per wave (plain stores: atomics on shared words would stall the run)
-                unsigned long long* rec = a.trace + 8ull * (t0 >> 6);
-                for (int k = 0; k < 5; ++k) rec[k] += tr_acc[k];
-                rec[5] += __builtin_amdgcn_s_memtime() - tr_t0;
-                rec[6] += 1ull;
-            }
-        }
-    };
-    if constexpr (TRACE) tr_t0 = tr_mark = __builtin_amdgcn_s_memtime();
+    DIAG diag(a, t0 >> 6);           // (NoDiag in every product kernel: see the top of this file)
 
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t id = a.base + t0;
@@ -1104,7 +1031,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
         iy = f32_as_i32(pos.y / a.grid.unit);
         ghost = iy < a.band_lo || iy >= a.band_hi;
         if (!ghost) {
-            if (ABL && (a.ablate & 1)) e = mk(1.0f, 0.0f);
+            if (diag.off(1)) e = mk(1.0f, 0.0f);
             else e = goal_direction<MODE>(a.field, pos, destination); // :107-108
             acc = acc + vdiv<MODE>(e * desired_speed - vel, 0.5f); // :109
             int32_t y_start = max(iy - 1, 0), y_end = min(iy + 1, a.grid.rows - 1); // :117-118
@@ -1120,7 +1047,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
             }
         }
     }
-    const uint32_t cnt = (ABL && (a.ablate & 4)) ? 0u : n0 + n1 + n2;
+    const uint32_t cnt = diag.off(4) ? 0u : n0 + n1 + n2;
     uint32_t max_cnt = cnt;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, off, 64));
@@ -1132,7 +1059,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
     // address, already in cache): phase 1 then has no divergent branch around its loads
     const uint32_t id_safe = valid ? id : a.base;
 
-    tr_lap(0);
+    diag.lap(0);
     for (uint32_t base = 0; base < max_cnt; base += SLOTS) {
         // ---- phase 1: cutoff test + compaction ---------------------------------------
         // three unrolled sub-passes so that the SLOTS position loads, then the SLOTS
@@ -1176,7 +1103,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
         queue[(uint32_t)(SLOTS * 64) + lane] = make_float2(-0.0f, -0.0f);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tr_lap(1);
+        diag.lap(1);
 
         // ---- phase 2: one pair force per lane, no divergence ------------------------------
         for (uint32_t q0 = 0; q0 < qlen; q0 += 64) {
@@ -1187,7 +1114,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
             // (PEDONI_ABLATE & 8, diagnostics: every lane reads the velocity record of ITS OWN agent --
             // a coalesced, cached load in place of the gather; results wrong, arithmetic the same)
             const float4 vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.velx) +
-                                                               (((ABL && (a.ablate & 8)) ? id_safe : (w & 0x03ffffffu)) << 4));
+                                                               ((diag.off(8) ? id_safe : (w & 0x03ffffffu)) << 4));
             // the owner's goal direction, straight from its registers (every lane takes part)
             const int own = (int)(w >> 26);
             const float eo_x = __shfl(e.x, own, 64), eo_y = __shfl(e.y, own, 64);
@@ -1197,13 +1124,13 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
                 // (PEDONI_ABLATE & 16, diagnostics: no pair arithmetic -- the loads, the queue and the
                 // ordered sums stay)
                 v2 f = mk(en.x + vn.x + eo_x, en.y + vn.y + eo_y + vn.z);
-                if (!(ABL && (a.ablate & 16))) f = pair_force_value<MODE>(mk(en.x, en.y), mk(eo_x, eo_y), mk(vn.x, vn.y), vn.z, tab);
+                if (!diag.off(16)) f = pair_force_value<MODE>(mk(en.x, en.y), mk(eo_x, eo_y), mk(vn.x, vn.y), vn.z, tab);
                 queue[q] = make_float2(f.x, f.y);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tr_lap(2);
+        diag.lap(2);
 
         // ---- phase 3: ordered accumulation (sfm.rs:153) ---------------------------------
         // all SLOTS entries are fetched first (a slot that did not pass reads the lane's dump
@@ -1215,7 +1142,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
         for (int k = 0; k < SLOTS; ++k) acc = acc + mk(fr[k].x, fr[k].y);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tr_lap(3);
+        diag.lap(3);
     }
 
     if (!valid) {
@@ -1224,7 +1151,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
     }
     // (the epilogue below runs per lane; the trace is flushed by lane 0 wherever it leaves)
     if (!valid) {
-        tr_flush(); on_exit();
+        diag.flush(); on_exit();
         return;
     }
     if (ghost) {                                                  // ghost row: never integrated
@@ -1234,7 +1161,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
             a.velx_out[id] = vv;
             if (a.key_next) a.key_next[id] = DEAD;
         }
-        tr_flush(); on_exit();
+        diag.flush(); on_exit();
         return;
     }
 
@@ -1253,7 +1180,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
     }
     // the early-out flags of that cell (one word, neighbouring lanes read neighbouring words)
     const uint32_t cflags = cell_flags_of(a, ix, iy);
-    if (ABL && (a.ablate & 2)) {}
+    if (diag.off(2)) {}
     else if (a.use_distance_map) {
         // sfm.rs:188-192.  Flagged cell: exp(-distance / 0.2) is exactly 0 and the direction finite, the term
         // is (+-0, +-0), and acc + (+-0) == acc bit for bit -- unless a component of acc is itself +-0 (or
@@ -1263,7 +1190,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
     }
     else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
 
-    if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); tr_flush(); on_exit(); return; }
+    if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); diag.flush(); on_exit(); return; }
 
     // integrator, sfm.rs:245-254
     v2 vel_prev = vel;
@@ -1287,17 +1214,17 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
             const bool far = abs(cx - ix) > 1 || abs(cy - iy) > 1;
             // = survives(a.field, pos, dest_k): certain without a sample when the flag of the agent's map is
             // set and the step ended inside the 3 x 3 cells the flag speaks for, at a position that is a number
-            if ((ABL && (a.ablate & 32)) || despawn_test_passes(a.field, cflags, dest_k, far, pos)) {
+            if (diag.off(32) || despawn_test_passes(a.field, cflags, dest_k, far, pos)) {
                 k = (uint32_t)cy * (uint32_t)a.grid.cols + (uint32_t)cx;
                 if (far) atomicOr(&a.flags->far[a.parity_next], 1u);
             }
         }
         a.key_next[id] = k;
-        if (ABL && (a.ablate & 64)) { if (k != DEAD) atomicAdd(&a.cell_count[k], 1u); }     // (diagnostics: no row counts)
-        else if (ABL && (a.ablate & 128)) { if (k == 0xfffffffeu) atomicAdd(&a.cell_count[k], 1u); }   // (no counts at all)
+        if (diag.off(64)) { if (k != DEAD) atomicAdd(&a.cell_count[k], 1u); }     // (diagnostics: no row counts)
+        else if (diag.off(128)) { if (k == 0xfffffffeu) atomicAdd(&a.cell_count[k], 1u); }   // (no counts at all)
         else count_key(a.cell_count, a.row_count, k != DEAD, k, (uint32_t)cy);
     }
-    tr_flush(); on_exit();
+    diag.flush(); on_exit();
 }
 
 // LDS of one force-kernel block: the exp table and one pair queue per wave
@@ -1311,13 +1238,13 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
     __syncthreads()
 
 // one tile per wave, tiles dealt by the hardware's workgroup order (XCD-contiguous by default)
-template <int MODE, int SLOTS, bool TRACE = false, bool ABL = false>
+template <int MODE, int SLOTS, class DIAG = NoDiag>
 __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
 {
     PEDONI_FORCE_LDS(SLOTS);
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
-    force_queue_tile<MODE, SLOTS, TRACE, ABL>(a, block * blockDim.x + threadIdx.x, queue_all[wave], who_all[wave], tab);
+    force_queue_tile<MODE, SLOTS, DIAG>(a, block * blockDim.x + threadIdx.x, queue_all[wave], who_all[wave], tab);
 }
 
 // ---- K_FORCE for SMALL crowds: G lanes per agent ----------------------------
@@ -1357,33 +1284,11 @@ template <int G> __device__ __forceinline__ float group_lane(float v, int g)
     return __int_as_float(r);
 }
 
-template <int MODE, int SLOTS, int G, bool TRACE = false>
+template <int MODE, int SLOTS, int G, class DIAG = NoDiag>
 __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const uint32_t tile, float2* __restrict__ queue,
                                                        uint32_t* __restrict__ who, const uint64_t* __restrict__ tab)
 {
-    // TRACE (diagnostics build): per wave, the shader cycles spent in prologue / phase 1 / 2 / 3 /
-    // epilogue, its lifetime, 1, and its start stamp: a.trace[8 * tile + 0..7]
-    unsigned long long tr_t0 = 0, tr_mark = 0, tr_acc[5] = {0, 0, 0, 0, 0};
-    auto tr_lap = [&](int which) {
-        if constexpr (TRACE) {
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            tr_acc[which] += now - tr_mark;
-            tr_mark = now;
-        }
-    };
-    auto tr_flush = [&]() {
-        if constexpr (TRACE) {
-            if ((threadIdx.x & 63u) == 0 && a.trace) {
-                tr_lap(4);
-                unsigned long long* rec = a.trace + 8ull * tile;
-                for (int k = 0; k < 5; ++k) rec[k] += tr_acc[k];
-                rec[5] += __builtin_amdgcn_s_memtime() - tr_t0;
-                rec[6] += 1ull;
-                rec[7] = tr_t0;
-            }
-        }
-    };
-    if constexpr (TRACE) tr_t0 = tr_mark = __builtin_amdgcn_s_memtime();
+    DIAG diag(a, tile);
     constexpr uint32_t PER_WAVE = 64u / (uint32_t)G;
     const uint32_t lane = threadIdx.x & 63u, sub = lane & (uint32_t)(G - 1);
     const bool writer = sub == 0;                 // the group's lane that stores and counts
@@ -1461,7 +1366,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
     const uint32_t n01 = n0 + n1, r1s = r1 - n0, r2s = r2 - n01;
     const uint32_t id_safe = valid ? id : a.base;
 
-    tr_lap(0);
+    diag.lap(0);
     // one batch = SLOTS slots per lane = G * SLOTS consecutive slots of the agent
     for (uint32_t base = 0; base < max_cnt; base += (uint32_t)(G * SLOTS)) {
         // ---- phase 1: this lane's share of the batch: slots base + sub, base + sub + G, ... ----
@@ -1497,7 +1402,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
         queue[(uint32_t)(SLOTS * 64) + lane] = make_float2(-0.0f, -0.0f);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tr_lap(1);
+        diag.lap(1);
 
         // ---- phase 2: one pair force per lane (as in the one-lane kernel) ---------------------
         for (uint32_t q0 = 0; q0 < qlen; q0 += 64) {
@@ -1515,7 +1420,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tr_lap(2);
+        diag.lap(2);
 
         // ---- phase 3: the group's ordered sum, formed alike on each of its lanes (sfm.rs:153) ----
         float2 fr[SLOTS];
@@ -1529,13 +1434,13 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tr_lap(3);
+        diag.lap(3);
     }
 
     if (!valid) {
         // slot of a despawned agent (whole-array launches only: segments end at live agents)
         if (writer && a.key_next && a.seg_row[0][0] < 0 && id < a.key_end) a.key_next[id] = DEAD;
-        tr_flush();
+        diag.flush();
         return;
     }
     if (ghost) {                                                  // ghost row: never integrated
@@ -1545,7 +1450,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
             a.velx_out[id] = vv;
             if (a.key_next) a.key_next[id] = DEAD;
         }
-        tr_flush();
+        diag.flush();
         return;
     }
     uint32_t dest_k = 0;
@@ -1554,7 +1459,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
     if (a.use_distance_map) acc = acc + wall;                     // (= obstacle_force_map: direction * k, lane 1's)
     else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
 
-    if (a.acc_out) { if (writer) a.acc_out[id] = make_float2(acc.x, acc.y); tr_flush(); return; }
+    if (a.acc_out) { if (writer) a.acc_out[id] = make_float2(acc.x, acc.y); diag.flush(); return; }
 
     // integrator, sfm.rs:245-254
     v2 vel_prev = vel;
@@ -1583,7 +1488,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
         if (writer) a.key_next[id] = k;
         count_key(a.cell_count, a.row_count, writer && k != DEAD, k, (uint32_t)cy);
     }
-    tr_flush();
+    diag.flush();
 }
 
 template <int MODE, int SLOTS, int G>
@@ -1595,53 +1500,8 @@ __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_group(ForceA
     force_queue_tile_group<MODE, SLOTS, G>(a, block * FORCE_WAVES + wave, queue_all[wave], who_all[wave], tab);
 }
 
-#ifdef PEDONI_DIAGNOSTICS
-template <int MODE, int SLOTS, int G>
-__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_group_trace(ForceArgs a)
-{
-    PEDONI_FORCE_LDS(SLOTS);
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
-    force_queue_tile_group<MODE, SLOTS, G, true>(a, block * FORCE_WAVES + wave, queue_all[wave], who_all[wave], tab);
-}
-#endif
 
-#ifdef PEDONI_DIAGNOSTICS
-// experiment: ONE wave per workgroup (the dispatcher refills at wave granularity, no block barrier)
-template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(64, 7) __attribute__((amdgpu_num_sgpr(94)))
-force_kernel_queue_w1(ForceArgs a)
-{
-    __shared__ uint64_t tab[32];
-    __shared__ float2 queue1[SLOTS * 64 + 64];
-    __shared__ uint32_t who1[SLOTS * 64 + 64];
-    if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // XCD-contiguous order at the granularity of 4 tiles, as the 4-wave kernel's
-    const uint32_t quad = a.xcd_remap ? xcd_contiguous_block(blockIdx.x >> 2, (gridDim.x + 3u) >> 2) : (blockIdx.x >> 2);
-    force_queue_tile<MODE, SLOTS>(a, (quad * 4u + (blockIdx.x & 3u)) * 64u + threadIdx.x, queue1, who1, tab);
-}
-#endif
 
-#ifdef PEDONI_DIAGNOSTICS
-// diagnostic build of the 7-wave kernel with the extended ablation switches (PEDONI_ABLATE bits 8
-// and up; tools/ablate_launch.py): a build of its own, so that the product kernels carry none of it
-template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
-force_kernel_queue_ablate(ForceArgs a)
-{
-    force_queue_body<MODE, SLOTS, false, true>(a);
-}
-
-// diagnostic build of the 7-wave kernel with per-phase cycle accounting (see TRACE above)
-template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
-force_kernel_queue_trace(ForceArgs a)
-{
-    force_queue_body<MODE, SLOTS, true>(a);
-}
-#endif
 
 template <int MODE, int SLOTS>
 __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue(ForceArgs a)
@@ -1739,7 +1599,7 @@ __device__ __forceinline__ void force_edge_first_body(const ForceArgs& a)
     }
     PEDONI_FORCE_LDS(SLOTS);          // (its barrier publishes `ep` too)
     const uint32_t wave = threadIdx.x >> 6;
-    force_queue_tile<MODE, SLOTS, false, false, EdgeExit>(a, tile * blockDim.x + threadIdx.x, queue_all[wave], who_all[wave], tab,
+    force_queue_tile<MODE, SLOTS, NoDiag, EdgeExit>(a, tile * blockDim.x + threadIdx.x, queue_all[wave], who_all[wave], tab,
                                                           EdgeExit{&ep});
 }
 
@@ -1777,116 +1637,6 @@ force_kernel_queue_edge_first_s94(ForceArgs a) { force_edge_first_body<MODE, SLO
 template <int MODE, int SLOTS>
 __global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_edge_first(ForceArgs a) { force_edge_first_body<MODE, SLOTS>(a); }
 
-#ifdef PEDONI_DIAGNOSTICS
-// ---- K_FORCE, persistent-wave forms: a MEASURED DEAD END, kept in the diagnostics build only -----
-// VERDICT r2 item 2 asked for the persistent form to be measured instead of argued away: a grid of
-// what the chip holds at once (w waves x 1024 SIMDs), every wave working through 64-agent tiles of
-// its XCD's contiguous range -- first tile static, the next ones from a per-XCD ticket word -- so
-// that a SIMD keeps its waves until the tiles are gone.  Same tile function, same bits (the parity
-// suites pass with PEDONI_FORCE_PERSIST set).  Result on MI355X, N = 1e6, exact mode, force kernel
-// (profiles/r03_persist_ab.txt; one-tile-per-wave kernel: 88.7 us at 7 waves, 92.5 at 6):
-//   * tickets by agent-scope atomicAdd, drawn between tiles: 172-226 us.  A returning atomic is
-//     ordered with the wave's loads (vmcnt), and an agent-scope one executes at the memory side,
-//     behind the ~1e6 count atomics the kernel itself issues: ~25 us per draw.
-//   * the next ticket requested before the tile and read after it: 112-137 us (every load of the
-//     tile issued after the draw still returns behind it).
-//   * the draw at workgroup scope (executes in the XCD's own L2; only waves of that XCD draw from
-//     that word; no stealing): 105-112 us.
-//   * no tickets at all, static tile strides: 95.1 us at 6 waves (92.5 without the loop), 97.2 at
-//     5, 104.9 at 7.  At the 7-wave budget (72 VGPRs, 94 SGPRs) the tile function has not one
-//     register to spare: whatever is carried around it -- even with the loop state parked in LDS
-//     and the arguments re-read from the kernarg segment per tile -- costs 64-80 bytes of scratch
-//     per lane inside the tile's loops.
-// The hardware's dispatcher already refills a CU as workgroups retire; keeping the waves brings
-// nothing this kernel can use, and costs registers it does not have.  Not a product path.
-template <int MODE, int SLOTS>
-__device__ __forceinline__ void force_persist_body()
-{
-#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the symbol: address space 4 is a device notion)
-    PEDONI_FORCE_LDS(SLOTS);
-    // The arguments are re-read from the kernarg segment for every tile (scalar loads, scalar
-    // cache): held across the loop they are ~50 SGPRs live through every tile on top of the tile's
-    // own, which the compiler spills to VGPR lanes inside the tile's loops.
-    typedef const ForceArgs __attribute__((address_space(4))) KArgs;
-    KArgs* pa = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    // range x: tiles [x * q + min(x, r), + q + (x < r)); its first n_static(x) tiles are the static
-    // first tiles of the waves whose home it is (blocks x, x + 8, ...: dealt round-robin to the XCDs)
-    auto n_static = [&](uint32_t x) { return ((gridDim.x + 7u - x) >> 3) * (uint32_t)FORCE_WAVES; };
-    uint32_t home = blockIdx.x & 7u;
-    uint32_t t = (blockIdx.x >> 3) * (uint32_t)FORCE_WAVES + wave;     // static first tile
-    for (;;) {
-        asm volatile("" : "+s"(pa));          // (opaque: the arguments are re-read per tile, not carried around the loop)
-        const uint32_t n_tiles = pa->n_tiles, q = n_tiles / 8u, r = n_tiles % 8u;
-        if (t < q + (home < r ? 1u : 0u)) {
-            // the NEXT ticket is requested before this tile is worked on and read after it: a returning
-            // atomic waits (vmcnt, in order) for every store and count atomic issued before it, i.e. a
-            // draw BETWEEN two tiles waited for the whole tail of the tile before it -- ~28 us per
-            // draw, measured: the loop ran at half the speed of the same loop with static tiles
-            uint32_t drawn = 0;
-            if (lane == 0)
-                drawn = __hip_atomic_fetch_add(&pa->tickets[home * TICKET_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const ForceArgs a = *pa;
-            force_queue_tile<MODE, SLOTS>(a, (home * q + min(home, r) + t) * 64u + lane, queue_all[wave], who_all[wave], tab);
-            t = __builtin_amdgcn_readfirstlane(drawn) + n_static(home);
-        } else {
-            break;
-        }
-    }
-#endif
-}
-
-// bisecting experiment: the same loop with STATIC tiles (tile, tile + waves of the range, ...): no
-// tickets, no atomics, no stealing
-template <int MODE, int SLOTS>
-__device__ __forceinline__ void force_static_body()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    PEDONI_FORCE_LDS(SLOTS);
-    typedef const ForceArgs __attribute__((address_space(4))) KArgs;
-    KArgs* pa = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t home = blockIdx.x & 7u;
-    const uint32_t step = ((gridDim.x + 7u - home) >> 3) * (uint32_t)FORCE_WAVES;
-    for (uint32_t t = (blockIdx.x >> 3) * (uint32_t)FORCE_WAVES + wave;; t += step) {
-        asm volatile("" : "+s"(pa));
-        const uint32_t n_tiles = pa->n_tiles, q = n_tiles / 8u, r = n_tiles % 8u;
-        if (t >= q + (home < r ? 1u : 0u)) break;
-        const ForceArgs a = *pa;
-        force_queue_tile<MODE, SLOTS>(a, (home * q + min(home, r) + t) * 64u + lane, queue_all[wave], who_all[wave], tab);
-    }
-#endif
-}
-template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_static5(ForceArgs) { force_static_body<MODE, SLOTS>(); }
-template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS, 6) force_kernel_queue_static6(ForceArgs) { force_static_body<MODE, SLOTS>(); }
-template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
-force_kernel_queue_static7(ForceArgs) { force_static_body<MODE, SLOTS>(); }
-
-// at the one-tile-per-wave kernel's budget (7 waves per SIMD: 72 VGPRs, 94 SGPRs) ...
-template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
-force_kernel_queue_persist(ForceArgs)
-{
-    force_persist_body<MODE, SLOTS>();
-}
-
-// ... at 6 waves per SIMD (<= 80 VGPRs, default SGPRs) ...
-template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS, 6) force_kernel_queue_persist6(ForceArgs)
-{
-    force_persist_body<MODE, SLOTS>();
-}
-
-// ... and with no cap at all (93 VGPRs: 5 waves per SIMD, nothing spilled)
-template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_persist5(ForceArgs)
-{
-    force_persist_body<MODE, SLOTS>();
-}
-#endif // PEDONI_DIAGNOSTICS
 
 // ---- on-device periodic spawning (Simulator::tick, lib.rs:67-85 + sfm.rs:49-56) ---------------
 // One thread replays, draw for draw, what the host does each tick: per periodic spawner
@@ -2088,3 +1838,7 @@ __global__ void halo_unpack_kernel(const uint32_t* __restrict__ from_below,
 }
 
 } // namespace pedoni
+
+#ifdef PEDONI_DIAGNOSTICS
+#include "kernels_diag.hpp"
+#endif

@@ -1,0 +1,273 @@
+// kernels_diag.hpp -- diagnostics-only kernels and hooks: included by kernels.hpp under PEDONI_DIAGNOSTICS,
+// i.e. built into libpedoni_hip_diag.so only (tests and tools load it; the product library has none of this).
+//   * the policy objects that time a wave's phases (TraceDiag) or switch parts of a kernel off for ablation
+//     runs (SwitchDiag) -- the product kernels are instantiated with NoDiag (kernels.hpp);
+//   * instantiations of the force kernel with them; dispatch-cost probes of the place kernel;
+//   * measured dead ends kept for the record: one wave per workgroup, the persistent-wave forms.
+#pragma once
+
+namespace pedoni {
+
+// TraceDiag (PEDONI_FORCE_TRACE=1): every wave adds the shader cycles (s_memtime) it spent in the prologue, in
+// phases 1 / 2 / 3 and in the epilogue to its own record a.trace[8 * wave + 0..4], its lifetime to [5] and 1 to
+// [6] -- where a wave's WALL time goes, waiting and being passed over by the arbiter included -- and stores in
+// [7] when it started and how long it lived on the 100 MHz clock every XCD shares (s_memtime is per XCD,
+// seconds apart): start in the low 40 bits, duration above (tools/force_trace.py, force_timeline.py, group_trace.py).
+struct TraceDiag {
+    const ForceArgs& a;
+    uint32_t wave;                                   // (wave-uniform, like the stamps: all of this lives in SGPRs)
+    unsigned long long t0, rt0, mark, acc[5];
+    __device__ __forceinline__ TraceDiag(const ForceArgs& args, uint32_t w)
+        : a(args), wave((uint32_t)__builtin_amdgcn_readfirstlane((int)w)), acc{0, 0, 0, 0, 0}
+    {
+        t0 = mark = __builtin_amdgcn_s_memtime();
+        rt0 = wall_clock64();
+    }
+    __device__ __forceinline__ void lap(int which)
+    {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        acc[which] += now - mark;
+        mark = now;
+    }
+    // (called wherever lanes leave the tile: the wave's lane 0 writes the record, plain stores -- atomics on
+    // shared words would stall the run)
+    __device__ __forceinline__ void flush()
+    {
+        if ((threadIdx.x & 63u) != 0 || !a.trace) return;
+        lap(4);
+        unsigned long long* rec = a.trace + 8ull * wave;
+        for (int k = 0; k < 5; ++k) rec[k] += acc[k];
+        rec[5] += __builtin_amdgcn_s_memtime() - t0;
+        rec[6] += 1ull;
+        rec[7] = (rt0 & 0xffffffffffull) | ((wall_clock64() - rt0) << 40);
+    }
+    __device__ __forceinline__ constexpr bool off(uint32_t) const { return false; }
+};
+
+// SwitchDiag: parts of a kernel switched off for timed launches (the results are wrong).
+//   force kernel (PEDONI_ABLATE / pedoni_hip_debug_set_ablate, tools/ablate_launch.py): 1 = no goal sampling, 2 = no
+//   obstacle term, 4 = no pairs, 8 / 16 = phase 2 without its gather / arithmetic, 32 = no despawn sampling,
+//   64 / 128 = no row / no counts;
+//   place kernel (bits 8 and up of the same word, tools/ablate_place.py, place_probe.py): 1 = no rank scan, 2 = no record
+//   move, 4 = no old-range loads, 8 = hardware workgroup order, 16 = return at once, 32 = key load + one store
+//   only, 64 = the bare record move, 128 = return before anything is read.  (The switch is a kernel argument:
+//   a __device__ variable set with hipMemcpyToSymbol never reached the kernel's scalar loads.)
+struct SwitchDiag {
+    uint32_t bits;
+    __device__ __forceinline__ explicit SwitchDiag(uint32_t b) : bits(b) {}
+    __device__ __forceinline__ SwitchDiag(const ForceArgs& a, uint32_t) : bits((uint32_t)a.ablate) {}
+    __device__ __forceinline__ void lap(int) {}
+    __device__ __forceinline__ void flush() {}
+    __device__ __forceinline__ bool off(uint32_t part) const { return (bits & part) != 0u; }
+};
+
+// ---- the force kernel with those hooks ---------------------------------------------------------------
+template <int MODE, int SLOTS, int G>
+__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_group_trace(ForceArgs a)
+{
+    PEDONI_FORCE_LDS(SLOTS);
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    force_queue_tile_group<MODE, SLOTS, G, TraceDiag>(a, block * FORCE_WAVES + wave, queue_all[wave], who_all[wave], tab);
+}
+
+// experiment: ONE wave per workgroup (the dispatcher refills at wave granularity, no block barrier)
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(64, 7) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_w1(ForceArgs a)
+{
+    __shared__ uint64_t tab[32];
+    __shared__ float2 queue1[SLOTS * 64 + 64];
+    __shared__ uint32_t who1[SLOTS * 64 + 64];
+    if (threadIdx.x < 32) tab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // XCD-contiguous order at the granularity of 4 tiles, as the 4-wave kernel's
+    const uint32_t quad = a.xcd_remap ? xcd_contiguous_block(blockIdx.x >> 2, (gridDim.x + 3u) >> 2) : (blockIdx.x >> 2);
+    force_queue_tile<MODE, SLOTS>(a, (quad * 4u + (blockIdx.x & 3u)) * 64u + threadIdx.x, queue1, who1, tab);
+}
+
+// diagnostic build of the 7-wave kernel with the extended ablation switches (PEDONI_ABLATE bits 8
+// and up; tools/ablate_launch.py): a build of its own, so that the product kernels carry none of it
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_ablate(ForceArgs a)
+{
+    force_queue_body<MODE, SLOTS, SwitchDiag>(a);
+}
+
+// diagnostic build of the 7-wave kernel with per-phase cycle accounting (TraceDiag above)
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_trace(ForceArgs a)
+{
+    force_queue_body<MODE, SLOTS, TraceDiag>(a);
+}
+
+// ---- dispatch-cost probes of the place kernel (tools/place_probe.sh) ------------------------------------
+__global__ void probe_empty_kernel(uint32_t* p, uint32_t n) { if (n == 0xffffffffu) p[0] = 1; }
+
+// the place kernel with its switches (pedoni_hip_debug_set_ablate bits 8 and up)
+__global__ void place_kernel_diag(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
+                             GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
+                             const uint32_t* __restrict__ cs_new, SortFlags* __restrict__ flags,
+                             uint32_t parity, uint32_t* __restrict__ cell_count, SoA a,
+                             uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed,
+                             uint32_t* __restrict__ row_count, int32_t row0, int32_t row1,
+                             uint32_t* __restrict__ status, uint32_t* __restrict__ tickets,
+                             uint32_t* __restrict__ done_count, uint32_t dbg)
+{
+    place_body(key, i0, n_total, grid, band, cs_old, cs_new, flags, parity, cell_count, a, slots, halo_consumed, row_count, row0, row1, status, tickets, done_count, SwitchDiag{dbg});
+}
+// (dispatch-cost probe: the same body under another name, so that a profile tells the probe launch from the real one)
+__global__ void place_kernel_probe(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
+                             GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
+                             const uint32_t* __restrict__ cs_new, SortFlags* __restrict__ flags,
+                             uint32_t parity, uint32_t* __restrict__ cell_count, SoA a,
+                             uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed,
+                             uint32_t* __restrict__ row_count, int32_t row0, int32_t row1,
+                             uint32_t* __restrict__ status, uint32_t* __restrict__ tickets,
+                             uint32_t* __restrict__ done_count, uint32_t dbg)
+{
+    place_body(key, i0, n_total, grid, band, cs_old, cs_new, flags, parity, cell_count, a, slots, halo_consumed, row_count, row0, row1, status, tickets, done_count, SwitchDiag{dbg});
+}
+
+// dispatch-cost probe: place_kernel's exact signature, an empty body (not one argument is read)
+__global__ void place_signature_only(const uint32_t* __restrict__, uint32_t, uint32_t, GridView, BandView, const uint32_t* __restrict__,
+                                     const uint32_t* __restrict__, SortFlags* __restrict__, uint32_t, uint32_t* __restrict__, SoA,
+                                     uint32_t* __restrict__, HaloIn* __restrict__, uint32_t* __restrict__, int32_t, int32_t,
+                                     uint32_t* __restrict__, uint32_t* __restrict__, uint32_t* __restrict__, uint32_t)
+{
+}
+
+// dispatch-cost probes, continued: the same signature reading ONE argument (the last) / ALL of them, then leaving
+__global__ void place_reads_one(const uint32_t* __restrict__, uint32_t, uint32_t, GridView, BandView, const uint32_t* __restrict__,
+                                const uint32_t* __restrict__, SortFlags* __restrict__, uint32_t, uint32_t* __restrict__ out, SoA,
+                                uint32_t* __restrict__, HaloIn* __restrict__, uint32_t* __restrict__, int32_t, int32_t,
+                                uint32_t* __restrict__, uint32_t* __restrict__, uint32_t* __restrict__, uint32_t dbg)
+{
+    if (dbg == 0x12345678u) out[0] = 1;
+}
+__global__ void place_reads_all(const uint32_t* __restrict__ a0, uint32_t a1, uint32_t a2, GridView g, BandView b, const uint32_t* __restrict__ a3,
+                                const uint32_t* __restrict__ a4, SortFlags* __restrict__ a5, uint32_t a6, uint32_t* __restrict__ out, SoA s,
+                                uint32_t* __restrict__ a7, HaloIn* __restrict__ a8, uint32_t* __restrict__ a9, int32_t a10, int32_t a11,
+                                uint32_t* __restrict__ a12, uint32_t* __restrict__ a13, uint32_t* __restrict__ a14, uint32_t dbg)
+{
+    unsigned long long sum = (unsigned long long)a0 + a1 + a2 + (unsigned long long)g.rows + g.cols + b.lo + b.hi + b.sharded + (unsigned long long)a3 +
+        (unsigned long long)a4 + (unsigned long long)a5 + a6 + (unsigned long long)s.pos_in + (unsigned long long)s.velx_in + (unsigned long long)s.dest_in +
+        (unsigned long long)s.pos_out + (unsigned long long)s.velx_out + (unsigned long long)s.dest_out + (unsigned long long)s.skey_out + s.fast +
+        (unsigned long long)a7 + (unsigned long long)a8 + (unsigned long long)a9 + a10 + a11 + (unsigned long long)a12 + (unsigned long long)a13 +
+        (unsigned long long)a14 + dbg;
+    if (sum == 0x1234567812345678ull) out[0] = 1;
+}
+
+// ---- K_FORCE, persistent-wave forms: a MEASURED DEAD END, kept in the diagnostics build only -----
+// VERDICT r2 item 2 asked for the persistent form to be measured instead of argued away: a grid of
+// what the chip holds at once (w waves x 1024 SIMDs), every wave working through 64-agent tiles of
+// its XCD's contiguous range -- first tile static, the next ones from a per-XCD ticket word -- so
+// that a SIMD keeps its waves until the tiles are gone.  Same tile function, same bits (the parity
+// suites pass with PEDONI_FORCE_PERSIST set).  Result on MI355X, N = 1e6, exact mode, force kernel
+// (profiles/r03_persist_ab.txt; one-tile-per-wave kernel: 88.7 us at 7 waves, 92.5 at 6):
+//   * tickets by agent-scope atomicAdd, drawn between tiles: 172-226 us.  A returning atomic is
+//     ordered with the wave's loads (vmcnt), and an agent-scope one executes at the memory side,
+//     behind the ~1e6 count atomics the kernel itself issues: ~25 us per draw.
+//   * the next ticket requested before the tile and read after it: 112-137 us (every load of the
+//     tile issued after the draw still returns behind it).
+//   * the draw at workgroup scope (executes in the XCD's own L2; only waves of that XCD draw from
+//     that word; no stealing): 105-112 us.
+//   * no tickets at all, static tile strides: 95.1 us at 6 waves (92.5 without the loop), 97.2 at
+//     5, 104.9 at 7.  At the 7-wave budget (72 VGPRs, 94 SGPRs) the tile function has not one
+//     register to spare: whatever is carried around it -- even with the loop state parked in LDS
+//     and the arguments re-read from the kernarg segment per tile -- costs 64-80 bytes of scratch
+//     per lane inside the tile's loops.
+// The hardware's dispatcher already refills a CU as workgroups retire; keeping the waves brings
+// nothing this kernel can use, and costs registers it does not have.  Not a product path.
+template <int MODE, int SLOTS>
+__device__ __forceinline__ void force_persist_body()
+{
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the symbol: address space 4 is a device notion)
+    PEDONI_FORCE_LDS(SLOTS);
+    // The arguments are re-read from the kernarg segment for every tile (scalar loads, scalar
+    // cache): held across the loop they are ~50 SGPRs live through every tile on top of the tile's
+    // own, which the compiler spills to VGPR lanes inside the tile's loops.
+    typedef const ForceArgs __attribute__((address_space(4))) KArgs;
+    KArgs* pa = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // range x: tiles [x * q + min(x, r), + q + (x < r)); its first n_static(x) tiles are the static
+    // first tiles of the waves whose home it is (blocks x, x + 8, ...: dealt round-robin to the XCDs)
+    auto n_static = [&](uint32_t x) { return ((gridDim.x + 7u - x) >> 3) * (uint32_t)FORCE_WAVES; };
+    uint32_t home = blockIdx.x & 7u;
+    uint32_t t = (blockIdx.x >> 3) * (uint32_t)FORCE_WAVES + wave;     // static first tile
+    for (;;) {
+        asm volatile("" : "+s"(pa));          // (opaque: the arguments are re-read per tile, not carried around the loop)
+        const uint32_t n_tiles = pa->n_tiles, q = n_tiles / 8u, r = n_tiles % 8u;
+        if (t < q + (home < r ? 1u : 0u)) {
+            // the NEXT ticket is requested before this tile is worked on and read after it: a returning
+            // atomic waits (vmcnt, in order) for every store and count atomic issued before it, i.e. a
+            // draw BETWEEN two tiles waited for the whole tail of the tile before it -- ~28 us per
+            // draw, measured: the loop ran at half the speed of the same loop with static tiles
+            uint32_t drawn = 0;
+            if (lane == 0)
+                drawn = __hip_atomic_fetch_add(&pa->tickets[home * TICKET_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const ForceArgs a = *pa;
+            force_queue_tile<MODE, SLOTS>(a, (home * q + min(home, r) + t) * 64u + lane, queue_all[wave], who_all[wave], tab);
+            t = __builtin_amdgcn_readfirstlane(drawn) + n_static(home);
+        } else {
+            break;
+        }
+    }
+#endif
+}
+
+// bisecting experiment: the same loop with STATIC tiles (tile, tile + waves of the range, ...): no
+// tickets, no atomics, no stealing
+template <int MODE, int SLOTS>
+__device__ __forceinline__ void force_static_body()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    PEDONI_FORCE_LDS(SLOTS);
+    typedef const ForceArgs __attribute__((address_space(4))) KArgs;
+    KArgs* pa = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t home = blockIdx.x & 7u;
+    const uint32_t step = ((gridDim.x + 7u - home) >> 3) * (uint32_t)FORCE_WAVES;
+    for (uint32_t t = (blockIdx.x >> 3) * (uint32_t)FORCE_WAVES + wave;; t += step) {
+        asm volatile("" : "+s"(pa));
+        const uint32_t n_tiles = pa->n_tiles, q = n_tiles / 8u, r = n_tiles % 8u;
+        if (t >= q + (home < r ? 1u : 0u)) break;
+        const ForceArgs a = *pa;
+        force_queue_tile<MODE, SLOTS>(a, (home * q + min(home, r) + t) * 64u + lane, queue_all[wave], who_all[wave], tab);
+    }
+#endif
+}
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_static5(ForceArgs) { force_static_body<MODE, SLOTS>(); }
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 6) force_kernel_queue_static6(ForceArgs) { force_static_body<MODE, SLOTS>(); }
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_static7(ForceArgs) { force_static_body<MODE, SLOTS>(); }
+
+// at the one-tile-per-wave kernel's budget (7 waves per SIMD: 72 VGPRs, 94 SGPRs) ...
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 7) __attribute__((amdgpu_num_sgpr(94)))
+force_kernel_queue_persist(ForceArgs)
+{
+    force_persist_body<MODE, SLOTS>();
+}
+
+// ... at 6 waves per SIMD (<= 80 VGPRs, default SGPRs) ...
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS, 6) force_kernel_queue_persist6(ForceArgs)
+{
+    force_persist_body<MODE, SLOTS>();
+}
+
+// ... and with no cap at all (93 VGPRs: 5 waves per SIMD, nothing spilled)
+template <int MODE, int SLOTS>
+__global__ void __launch_bounds__(FORCE_THREADS) force_kernel_queue_persist5(ForceArgs)
+{
+    force_persist_body<MODE, SLOTS>();
+}
+
+} // namespace pedoni

@@ -468,6 +468,12 @@ inline ForcePlan plan_force(const PedoniModel* m, uint32_t n, bool whole_array)
 // the shorter path brings.
 int group_by_size(uint32_t n) { return n < 40000u ? 4 : (n < 250000u ? 2 : 1); }
 
+} // namespace
+#ifdef PEDONI_DIAGNOSTICS
+#include "host_diag.hpp"
+#endif
+namespace {
+
 // sfm.rs:58-88 on the device
 int sort_despawn(PedoniModel* m)
 {
@@ -560,44 +566,21 @@ int sort_despawn(PedoniModel* m)
             Timed t(m, PEDONI_K_SLOT);
             if (t.rc) return t.rc;
             // (workgroups of 64 ... 1024 threads: the launch takes the same 17.6-18.9 us, tools/place_probe.sh)
+            uint32_t* const tickets = m->force_persist > 0 ? m->d_tickets : nullptr;
+            uint32_t* const done_count = host_knows_general ? nullptr : m->d_tickets + 8 * TICKET_STRIDE;
+            HaloIn* const consumed = (m->halo_cap || m->n_spawners) ? m->d_halo : nullptr;
+#ifdef PEDONI_DIAGNOSTICS
+            // (the place kernel with parts switched off, and the dispatch-cost probes behind it: host_diag.hpp)
+            if (m->place_ablate)
+                diag_launch_place(m, blocks_for(n_threads, bs), bs, i0, n_total, band, cs_old, cs_new, parity, soa, consumed, row0, row1,
+                                  tickets, done_count);
+            else
+#endif
             hipLaunchKernelGGL(place_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
                                m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
-                               (m->halo_cap || m->n_spawners) ? m->d_halo : nullptr, m->d_row_count, row0,
-                               row1, m->d_live + 1, m->force_persist > 0 ? m->d_tickets : nullptr,
-                               host_knows_general ? nullptr : m->d_tickets + 8 * TICKET_STRIDE, m->place_ablate);
+                               consumed, m->d_row_count, row0, row1, m->d_live + 1, tickets, done_count);
             m->tickets_fresh = true;
-#ifdef PEDONI_DIAGNOSTICS
-            if (m->place_ablate & 256u)      // (probe: the same body a second time under another name, with the
-                                             // switches of bits 16 and up: 128 = returning at once)
-                hipLaunchKernelGGL(place_kernel_probe, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
-                                   m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
-                                   m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
-                                   nullptr, m->d_row_count, row0, row1, m->d_live + 1, nullptr, nullptr,
-                                   (m->place_ablate >> 16) ? (m->place_ablate >> 16) : 128u);
-            if (m->place_ablate & 4096u) {   // (probes: the signature reading one / all of its arguments)
-                hipLaunchKernelGGL(place_reads_one, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
-                                   m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
-                                   m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
-                                   (HaloIn*)nullptr, m->d_row_count, row0, row1, m->d_live + 1, (uint32_t*)nullptr, (uint32_t*)nullptr, 128u);
-                hipLaunchKernelGGL(place_reads_all, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
-                                   m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
-                                   m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
-                                   (HaloIn*)nullptr, m->d_row_count, row0, row1, m->d_live + 1, (uint32_t*)nullptr, (uint32_t*)nullptr, 128u);
-            }
-            if (m->place_ablate & 2048u)     // (probe: place_kernel's signature, empty body, same grid and arguments)
-                hipLaunchKernelGGL(place_signature_only, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
-                                   m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
-                                   m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
-                                   (HaloIn*)nullptr, m->d_row_count, row0, row1, m->d_live + 1, (uint32_t*)nullptr, (uint32_t*)nullptr, 128u);
-            if (m->place_ablate & 1024u)     // (probe: a two-argument empty kernel on the same grid)
-                hipLaunchKernelGGL(probe_empty_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0, m->stream, m->d_slots, 1u);
-            if (m->place_ablate & 512u)      // (probe: a grid of 64 workgroups, returning at once)
-                hipLaunchKernelGGL(place_kernel, dim3(64), dim3(bs), 0,
-                                   m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
-                                   m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
-                                   nullptr, m->d_row_count, row0, row1, m->d_live + 1, nullptr, nullptr, 128u);
-#endif
         }
         if (host_knows_general) {
             Timed t(m, PEDONI_K_REORDER);
@@ -747,72 +730,11 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
             return PEDONI_OK;
         }
 #ifdef PEDONI_DIAGNOSTICS
-        // diagnostic instantiations (per-phase trace, ablation switches): a build of their own
-        if (m->d_trace && c.group > 1) {       // per-wave records of the group kernel (tools/group_trace.py)
-            const dim3 ggrid(blocks_for(n, FORCE_THREADS / (uint32_t)c.group));
-            if ((size_t)ggrid.x * FORCE_WAVES <= TRACE_WAVES) {
-                if (c.group == 2) hipLaunchKernelGGL((force_kernel_queue_group_trace<0, 8, 2>), ggrid, block, 0, stream, a);
-                else hipLaunchKernelGGL((force_kernel_queue_group_trace<0, 6, 4>), ggrid, block, 0, stream, a);
-                HIP_TRY(hipGetLastError());
-                return PEDONI_OK;
-            }
-        }
-        if (m->d_trace && (size_t)grid.x * FORCE_WAVES <= TRACE_WAVES) {
-            if (fast) hipLaunchKernelGGL((force_kernel_queue_trace<1, 6>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((force_kernel_queue_trace<0, 6>), grid, block, 0, stream, a);
-            HIP_TRY(hipGetLastError());
-            return PEDONI_OK;
-        }
-        if (m->ablate) {
-            if (fast) hipLaunchKernelGGL((force_kernel_queue_ablate<1, 6>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((force_kernel_queue_ablate<0, 6>), grid, block, 0, stream, a);
-            HIP_TRY(hipGetLastError());
-            return PEDONI_OK;
-        }
-#endif
-#ifdef PEDONI_DIAGNOSTICS
-        if (m->force_persist == 21 && part == 0) {     // experiment: one wave per workgroup
-            const dim3 g1(((blocks_for(n, 64) + 3u) / 4u) * 4u), b1(64);
-            if (fast) hipLaunchKernelGGL((force_kernel_queue_w1<1, 6>), g1, b1, 0, stream, a);
-            else hipLaunchKernelGGL((force_kernel_queue_w1<0, 6>), g1, b1, 0, stream, a);
-            HIP_TRY(hipGetLastError());
-            return PEDONI_OK;
-        }
-        // persistent-wave forms (kernels.hpp: a measured dead end, PEDONI_FORCE_PERSIST): whole-array
-        // launches right after a sort pass, whose place kernel zeroed the tile tickets
-        const bool persist = part == 0 && !on && m->tickets_fresh && c.build == ForceBuild::S94 && c.slots == 6 &&
-                             m->force_persist > 0;
-        if (persist) {
-            a.tickets = m->d_tickets;
-            a.n_tiles = blocks_for(n, 64);
-            m->tickets_fresh = false;
-            // the grid is what the chip holds at once: waves per SIMD (= blocks per CU) x 256 CUs
-            const uint32_t waves = m->force_persist == 5 || m->force_persist == 6 ? (uint32_t)m->force_persist : 7u;
-            const dim3 pgrid(std::min(blocks_for(n, FORCE_THREADS), waves * 256u));
-            if (m->force_persist >= 15 && m->force_persist <= 17) {
-                const dim3 sgrid(std::min(blocks_for(n, FORCE_THREADS), (uint32_t)(m->force_persist - 10) * 256u));
-                if (m->force_persist == 15) {
-                    if (fast) hipLaunchKernelGGL((force_kernel_queue_static5<1, 6>), sgrid, block, 0, stream, a);
-                    else hipLaunchKernelGGL((force_kernel_queue_static5<0, 6>), sgrid, block, 0, stream, a);
-                } else if (m->force_persist == 16) {
-                    if (fast) hipLaunchKernelGGL((force_kernel_queue_static6<1, 6>), sgrid, block, 0, stream, a);
-                    else hipLaunchKernelGGL((force_kernel_queue_static6<0, 6>), sgrid, block, 0, stream, a);
-                } else {
-                    if (fast) hipLaunchKernelGGL((force_kernel_queue_static7<1, 6>), sgrid, block, 0, stream, a);
-                    else hipLaunchKernelGGL((force_kernel_queue_static7<0, 6>), sgrid, block, 0, stream, a);
-                }
-            } else if (waves == 7) {
-                if (fast) hipLaunchKernelGGL((force_kernel_queue_persist<1, 6>), pgrid, block, 0, stream, a);
-                else hipLaunchKernelGGL((force_kernel_queue_persist<0, 6>), pgrid, block, 0, stream, a);
-            } else if (waves == 6) {
-                if (fast) hipLaunchKernelGGL((force_kernel_queue_persist6<1, 6>), pgrid, block, 0, stream, a);
-                else hipLaunchKernelGGL((force_kernel_queue_persist6<0, 6>), pgrid, block, 0, stream, a);
-            } else {
-                if (fast) hipLaunchKernelGGL((force_kernel_queue_persist5<1, 6>), pgrid, block, 0, stream, a);
-                else hipLaunchKernelGGL((force_kernel_queue_persist5<0, 6>), pgrid, block, 0, stream, a);
-            }
-            HIP_TRY(hipGetLastError());
-            return PEDONI_OK;
+        // (diagnostic instantiations -- per-phase trace, ablation switches, one wave per workgroup, the
+        // persistent forms -- selected by PEDONI_FORCE_TRACE / PEDONI_ABLATE / PEDONI_FORCE_PERSIST: host_diag.hpp)
+        {
+            int rc = PEDONI_OK;
+            if (diag_launch_force(m, a, c, n, grid, block, stream, fast, part, on != nullptr, &rc)) return rc;
         }
 #endif
         auto launch = [&](auto exact_kernel, auto fast_kernel) {
@@ -2041,7 +1963,7 @@ int pedoni_hip_debug_set_ablate(PedoniModel* m, uint32_t bits)
 {
     TRY(bind(m));
     m->ablate = (int)(bits & 0xffu);
-    m->place_ablate = bits >> 8;                          // bits 8 and up: place_kernel's switches (kernels.hpp PLACE_ABLATE)
+    m->place_ablate = bits >> 8;                          // bits 8 and up: place_kernel's switches (kernels_diag.hpp SwitchDiag)
     m->drop_graphs();
     return PEDONI_OK;
 }

@@ -31,9 +31,13 @@ m.debug_force_trace(reset=True)
 m.update_states()
 n_waves = (len(p) * int(grp) + 63) // 64
 rec = m.debug_force_trace_raw(n_waves + 8)
-rec = rec[rec[:, 6] > 0].astype(np.float64)
-life = rec[:, 5]; start = rec[:, 7] - rec[:, 7].min()
-GHZ = float(os.environ.get("SHADER_GHZ", "2.7"))     # s_memtime counts shader-clock cycles here (wave life 18.7 us by the counters)
+rec = rec[rec[:, 6] > 0]
+# rec[7]: start (low 40 bits) and duration (above) on the 100 MHz clock all XCDs share (s_memtime is per XCD)
+rt_start = (rec[:, 7] & np.uint64(0xffffffffff)).astype(np.float64)
+rt_life = (rec[:, 7] >> np.uint64(40)).astype(np.float64)
+rec = rec.astype(np.float64)
+GHZ = float(np.median(rec[:, 5] / np.maximum(rt_life, 1.0)) * 0.1)       # shader cycles per 10 ns, measured
+life = rec[:, 5]; start = (rt_start - rt_start.min()) * 10.0 * GHZ
 us = lambda c: c / (GHZ * 1e3)
 print(f"group {grp}: {len(rec)} waves; wave lifetime us: mean {us(life.mean()):.1f}, p50 {us(np.percentile(life,50)):.1f}, p90 {us(np.percentile(life,90)):.1f}, "
       f"p99 {us(np.percentile(life,99)):.1f}, max {us(life.max()):.1f}; start offsets us: p50 {us(np.percentile(start,50)):.2f}, p90 {us(np.percentile(start,90)):.2f}, "
