@@ -160,6 +160,12 @@ int pedoni_hip_neighbor_grid_shape(PedoniModel* m, uint32_t* rows, uint32_t* col
  * Both are exact statements about the maps -- a set bit never changes a result -- and the tests check
  * them against the oracle's samples.  Same calling convention as neighbor_grid_indices. */
 int pedoni_hip_cell_flags(PedoniModel* m, uint32_t* out, uint32_t cap, uint32_t* len);
+/* [ext] the workgroup order of the force launch ("heaviest tiles first": a tile = 256 consecutive sorted
+ * agents; placement only, results do not depend on it) as the last sort pass built it, and the per-tile
+ * weights (candidate counts of the tile's 256 lanes) currently stored -- those of the
+ * last force launch, i.e. the input of the NEXT pass's order.  *n_blocks = 0 when the launch keeps the plain
+ * order (small crowds, bands, PEDONI_NO_TILE_ORDER=1); order[b] = tile of hardware workgroup b. */
+int pedoni_hip_tile_order(PedoniModel* m, uint32_t* order, uint32_t* tile_weight, uint32_t cap, uint32_t* n_blocks);
 /* [ext] accelerations of sfm.rs:93-241 for the current sorted state (no integration) */
 int pedoni_hip_calc_accelerations(PedoniModel* m, float* acc_xy, uint32_t cap);
 

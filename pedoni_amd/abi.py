@@ -31,7 +31,7 @@ SYMBOLS = [
     "pedoni_hip_update_states", "pedoni_hip_list_pedestrians",
     "pedoni_hip_get_pedestrian_count", "pedoni_hip_append", "pedoni_hip_sort_despawn",
     "pedoni_hip_tick_n", "pedoni_hip_tick", "pedoni_hip_download", "pedoni_hip_clear",
-    "pedoni_hip_neighbor_grid_indices", "pedoni_hip_neighbor_grid_shape", "pedoni_hip_cell_flags",
+    "pedoni_hip_neighbor_grid_indices", "pedoni_hip_neighbor_grid_shape", "pedoni_hip_cell_flags", "pedoni_hip_tile_order",
     "pedoni_hip_calc_accelerations", "pedoni_hip_set_stream", "pedoni_hip_get_stream",
     "pedoni_hip_synchronize", "pedoni_hip_profile", "pedoni_hip_kernel_times",
     "pedoni_hip_kernel_name", "pedoni_hip_set_band", "pedoni_hip_halo_bytes",
@@ -363,6 +363,17 @@ class HipModel:
             _check(self._lib, self._lib.pedoni_hip_cell_flags(self._h, _ptr(out, C.c_uint32), C.c_uint32(n.value), C.byref(n)))
             return out.reshape(self.neighbor_grid_shape())
         return out
+
+    def tile_order(self):
+        """(order, weights): the force launch's workgroup -> tile map of the last sort pass and the per-tile weights
+        the last force launch left (include/pedoni_hip.h); two empty arrays when the plain order is in use."""
+        n = C.c_uint32(0)
+        _check(self._lib, self._lib.pedoni_hip_tile_order(self._h, None, None, 0, C.byref(n)))
+        order, weight = np.empty(n.value, np.uint32), np.empty(n.value, np.uint32)
+        if n.value:
+            _check(self._lib, self._lib.pedoni_hip_tile_order(self._h, _ptr(order, C.c_uint32), _ptr(weight, C.c_uint32),
+                                                               C.c_uint32(n.value), C.byref(n)))
+        return order, weight
 
     def neighbor_grid_indices(self) -> np.ndarray:
         n = C.c_uint32(0)

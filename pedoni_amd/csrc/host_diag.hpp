@@ -16,7 +16,7 @@ inline void diag_launch_place(PedoniModel* m, uint32_t blocks, uint32_t bs, uint
     HaloIn* const no_halo = nullptr;
     hipLaunchKernelGGL(place_kernel_diag, g, b, 0, m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old], m->d_cs[cs_new],
                        m->d_flags, parity, m->d_scan_in, soa, m->d_slots, consumed, m->d_row_count, row0, row1, m->d_live + 1,
-                       tickets, done_count, m->place_ablate);
+                       tickets, done_count, m->place_ablate);   // (no tile order in a diagnostic pass)
     if (m->place_ablate & 256u)      // the same body a second time under another name, with the switches of bits 16 and up (default: returning at once)
         hipLaunchKernelGGL(place_kernel_probe, g, b, 0, m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old], m->d_cs[cs_new],
                            m->d_flags, parity, m->d_scan_in, soa, m->d_slots, no_halo, m->d_row_count, row0, row1, m->d_live + 1, none, none,

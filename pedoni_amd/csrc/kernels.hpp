@@ -552,6 +552,80 @@ __device__ __forceinline__ void reorder_body(const uint32_t* __restrict__ key, u
                                              uint32_t* __restrict__ cell_count, const SoA& a,
                                              uint32_t first_thread, uint32_t n_threads);
 
+// ---- heaviest tiles first (the force launch's workgroup order) -----------------------------------------
+// A force launch is ~2.2 generations of workgroups and ends with a drain: after the last workgroup has been
+// dispatched the chip empties over one wave lifetime (tools/force_timeline.py: 28 of 83 us for the uniform
+// crowd, 51 of 120 us for the bottleneck's counter-flow, whose densest waves live three times as long as its
+// median ones).  What is dispatched LAST should therefore be what ends soonest.  Every wave of a force launch
+// stores its lanes' candidate count (ForceArgs.tile_weight: what the pair rounds of the wave follow); the crowd moves centimetres per tick, so that is next tick's cost too.  The next
+// sort pass turns the weights into a workgroup order, XCD by XCD (xcd_contiguous_block's chunks: every XCD
+// still works through its own contiguous eighth of the agents): a counting sort by weight class, heaviest
+// class first (classes a quarter of the mean weight wide, centred so that a uniform crowd is ONE class and
+// keeps the plain, L2-friendly ascending order).  Placement only: any weights give a bijection (it is a
+// permutation by construction), the results do not depend on it.
+// Runs in the first 8 workgroups of the place kernel (one per XCD chunk), which are dispatched first and are
+// long done when the launch's other 3900 are: no launch of its own.
+__device__ __forceinline__ uint32_t tile_weight_of(const uint32_t* __restrict__ wave_weight, uint32_t tile)
+{
+    const uint4 w = *reinterpret_cast<const uint4*>(wave_weight + 4u * tile);     // FORCE_WAVES = 4 waves per tile
+    return w.x + w.y + w.z + w.w;
+}
+// A tile is an INDEX range, not a place: its borders drift by tens of agents per tick (agents ahead of it in the
+// order change rows), so a jam of ~100 agents near a border is in this tile one tick and in its neighbour the
+// next -- 1 % of the bottleneck's tiles change weight by more than half the mean from one tick to the next
+// (tools/force_timeline.py).  A tile is therefore ranked by the heaviest of itself and its two neighbours:
+// ranking a tile too heavy only starts it early.
+// (block_exclusive_scan is defined above; 256 threads)
+constexpr uint32_t TILE_LEVELS = 64;      // weight classes, a quarter of the mean weight wide; the one around the mean is
+                                          // [0.875, 1.125) x mean: a uniform crowd's tiles all fall into it and keep their order
+constexpr uint32_t TILE_CHUNK_MAX = 4096; // tiles per XCD chunk the builder holds in LDS (8.4e6 agents per GPU; beyond: plain order)
+__device__ __forceinline__ void build_tile_order(uint32_t xcd, uint32_t n_blocks, const uint32_t* __restrict__ wave_weight,
+                                                 uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t lds[SCAN_THREADS / 64];
+    __shared__ uint32_t cursor[TILE_LEVELS];
+    __shared__ uint32_t wl[TILE_CHUNK_MAX];
+    const uint32_t q = n_blocks / 8u, r = n_blocks % 8u;
+    const uint32_t len = q + (xcd < r ? 1u : 0u);
+    const uint32_t first = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;     // = xcd_contiguous_block(xcd, n_blocks)
+    // the chunk's weights, once, into LDS (one round trip: the loads of a thread are independent), and their sum:
+    // tiles are ranked inside their XCD's chunk, so the chunk's own mean is the yardstick
+    uint32_t part = 0;
+    for (uint32_t j = threadIdx.x; j < len; j += blockDim.x) {
+        const uint32_t w = tile_weight_of(wave_weight, first + j);
+        wl[j] = w;
+        part += w;
+    }
+    if (threadIdx.x < TILE_LEVELS) cursor[threadIdx.x] = 0;
+    uint32_t total;
+    block_exclusive_scan(part, lds, total);            // (its barriers publish wl and cursor)
+    // class of a tile: heaviest first = class 0; level = round(4 w / mean) (64-bit: no overflow)
+    const unsigned long long n64 = len, tot64 = total ? total : 1u;
+    auto class_of = [&](uint32_t j) -> uint32_t {
+        uint32_t w = wl[j];
+        if (j > 0u) w = max(w, wl[j - 1u]);
+        if (j + 1u < len) w = max(w, wl[j + 1u]);
+        const unsigned long long level = (8ull * w * n64 + tot64) / (2ull * tot64);
+        return (TILE_LEVELS - 1u) - (uint32_t)(level < TILE_LEVELS - 1u ? level : TILE_LEVELS - 1u);
+    };
+    // pass 1: the chunk's tiles per class
+    for (uint32_t j = threadIdx.x; j < len; j += blockDim.x) atomicAdd(&cursor[class_of(j)], 1u);
+    __syncthreads();
+    // exclusive prefix over the classes: where each class starts in the chunk's order
+    const uint32_t mine = threadIdx.x < TILE_LEVELS ? cursor[threadIdx.x] : 0u;
+    uint32_t all;
+    const uint32_t begin = block_exclusive_scan(mine, lds, all);
+    if (threadIdx.x < TILE_LEVELS) cursor[threadIdx.x] = begin;
+    __syncthreads();
+    // pass 2: strips of 256 tiles in ascending order, a tile takes the next place of its class (inside a class
+    // the order is ascending from strip to strip and arbitrary inside a strip: placement only)
+    for (uint32_t j0 = 0; j0 < len; j0 += blockDim.x) {
+        const uint32_t j = j0 + threadIdx.x;
+        if (j < len) order[xcd + 8u * atomicAdd(&cursor[class_of(j)], 1u)] = first + j;
+        __syncthreads();
+    }
+}
+
 // Per-cell member counts are already in cell_count when the pass starts: every key that is
 // stored -- by the force kernel's tail, by K_KEY or by the halo unpack -- is followed by one
 // integer atomicAdd on its cell.  The scan turned them into cell_start (and zeroed them).
@@ -561,6 +635,12 @@ __device__ __forceinline__ void reorder_body(const uint32_t* __restrict__ key, u
 //  general form: a provisional slot by a second round of atomics on the (zeroed) counter;
 //    K_REORDER puts the cell in order and zeroes the counter again.
 
+struct TileOrder {               // (all null / 0: the force launch keeps the plain XCD-contiguous order)
+    const uint32_t* wave_weight; // per wave of the last force launch: the candidates of its 64 lanes
+    uint32_t* order;             // out: hardware workgroup -> tile, for a force launch of n_blocks workgroups
+    uint32_t n_blocks;
+};
+
 template <class DIAG>
 __device__ __forceinline__ void place_body(const uint32_t* __restrict__ key, uint32_t i0, uint32_t n_total,
                              GridView grid, BandView band, const uint32_t* __restrict__ cs_old,
@@ -569,9 +649,12 @@ __device__ __forceinline__ void place_body(const uint32_t* __restrict__ key, uin
                              uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed,
                              uint32_t* __restrict__ row_count, int32_t row0, int32_t row1,
                              uint32_t* __restrict__ status, uint32_t* __restrict__ tickets,
-                             uint32_t* __restrict__ done_count, const DIAG diag)
+                             uint32_t* __restrict__ done_count, TileOrder tiles, const DIAG diag)
 {
     if (diag.off(128)) return;                       // (diagnostics: before anything is read but the arguments)
+    // the workgroup order of the force launch that follows this pass, built beside the placement by the
+    // launch's first 8 workgroups (block-uniform branch)
+    if (tiles.order && blockIdx.x < 8u && blockDim.x == SCAN_THREADS) build_tile_order(blockIdx.x, tiles.n_blocks, tiles.wave_weight, tiles.order);
     // `done_count` != null: the host launches NO reorder kernel after this pass (steady state:
     // nothing appended, not a band) and a general-form pass that only the device knows of -- an agent
     // that moved more than one cell -- is put in order here, by the workgroup that finishes last:
@@ -674,9 +757,9 @@ __global__ void place_kernel(const uint32_t* __restrict__ key, uint32_t i0, uint
                              uint32_t* __restrict__ slots, HaloIn* __restrict__ halo_consumed,
                              uint32_t* __restrict__ row_count, int32_t row0, int32_t row1,
                              uint32_t* __restrict__ status, uint32_t* __restrict__ tickets,
-                             uint32_t* __restrict__ done_count)
+                             uint32_t* __restrict__ done_count, TileOrder tiles)
 {
-    place_body(key, i0, n_total, grid, band, cs_old, cs_new, flags, parity, cell_count, a, slots, halo_consumed, row_count, row0, row1, status, tickets, done_count, NoDiag{});
+    place_body(key, i0, n_total, grid, band, cs_old, cs_new, flags, parity, cell_count, a, slots, halo_consumed, row_count, row0, row1, status, tickets, done_count, tiles, NoDiag{});
 }
 
 // ---- K_REORDER (general form only) --------------------------------------------------------
@@ -779,6 +862,10 @@ struct ForceArgs {
     // despawn test is certain to pass anywhere in the 3 x 3 cells around, bit 31 = the wall term is +-0
     const uint32_t* cell_flags;
     int32_t xcd_remap; // XCD-contiguous block order (PEDONI_NO_XCD_REMAP=1 turns it off)
+    // heaviest tiles first (build_tile_order above): this launch's workgroup -> tile map (null: the plain
+    // XCD-contiguous order) and where every wave leaves its weight for the next tick's map (null: nowhere)
+    const uint32_t* tile_order;
+    uint32_t* tile_weight;
     // edge-first form (force_kernel_queue_edge_first, a band of a sharded run): the tiles holding the agents
     // of the rows below edge_row[0] and from edge_row[1] up are worked on by the FIRST workgroups; when
     // the last of those has stored its results, edge_flag (a device word another stream's edge_wait_kernel
@@ -1052,6 +1139,15 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, off, 64));
     max_cnt = __builtin_amdgcn_readfirstlane(max_cnt);
+    // this wave's weight for the next tick's workgroup order: its candidates, all lanes together (what the pair
+    // rounds of phase 2 follow; steadier from tick to tick than the fullest lane's count, which jumps by 60 %
+    // when a clump of agents crosses a tile boundary)
+    if (a.tile_weight) {
+        uint32_t sum_cnt = cnt;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum_cnt += (uint32_t)__shfl_xor((int)sum_cnt, off, 64);
+        if (lane == 0u) a.tile_weight[t0 >> 6] = sum_cnt;
+    }
 
     // candidate s of this lane: index r0 + s, r1 + (s - n0) or r2 + (s - n0 - n1)
     const uint32_t n01 = n0 + n1, r1s = r1 - n0, r2s = r2 - n01;
@@ -1243,7 +1339,7 @@ __device__ __forceinline__ void force_queue_body(const ForceArgs& a)
 {
     PEDONI_FORCE_LDS(SLOTS);
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t block = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t block = a.tile_order ? a.tile_order[blockIdx.x] : (a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x);
     force_queue_tile<MODE, SLOTS, DIAG>(a, block * blockDim.x + threadIdx.x, queue_all[wave], who_all[wave], tab);
 }
 

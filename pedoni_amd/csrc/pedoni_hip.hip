@@ -174,6 +174,12 @@ struct PedoniModel {
     uint32_t block_sums_cap = 0;
     uint32_t* d_row_count = nullptr; // members per grid row (top level of the row scan)
     uint32_t* d_cell_flags = nullptr; // per-cell early-out flags (kernels.hpp CELL_FLAG_*); null with PEDONI_NO_CELL_FLAGS=1
+    // heaviest tiles first (kernels.hpp build_tile_order): per-wave weights left by the last force launch, and the
+    // workgroup order the sort pass builds from them for the next one; PEDONI_NO_TILE_ORDER=1 turns it off
+    uint32_t* d_tile_weight = nullptr;
+    uint32_t* d_tile_order = nullptr;
+    uint32_t tile_order_blocks = 0;   // the force grid the current order was built for (0: none)
+    bool tile_order_on = true;
     uint32_t* d_tickets = nullptr;   // [8 * TICKET_STRIDE] = place_kernel's workgroups-done counter; in front of it, the
                                      // diagnostics build's 8 tile-ticket words, TICKET_STRIDE apart
     bool tickets_fresh = false;      // zeroed by the place kernel and not drawn from since
@@ -331,6 +337,8 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
     float4* nvel[2] = {nullptr, nullptr};
     uint32_t *ndest[2] = {nullptr, nullptr}, *nskey[2] = {nullptr, nullptr};
     uint32_t *nkey = nullptr, *nslots = nullptr, *nscan_in = nullptr, *ncs0 = nullptr, *nblock_sums = nullptr;
+    uint32_t *ntile_weight = nullptr, *ntile_order = nullptr;
+    const size_t n_tile_waves = (size_t)ncap / 64 + 8, n_tiles = (size_t)ncap / FORCE_THREADS + 8;
     int rc = PEDONI_OK;
     for (int k = 0; k < 2 && rc == PEDONI_OK; ++k) {
         rc = grab(&npos[k], ncap);
@@ -340,6 +348,10 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
     }
     if (rc == PEDONI_OK) rc = grab(&nkey, ncap);
     if (rc == PEDONI_OK) rc = grab(&nslots, ncap);
+    if (rc == PEDONI_OK) rc = grab(&ntile_weight, n_tile_waves);
+    if (rc == PEDONI_OK) rc = grab(&ntile_order, n_tiles);
+    if (rc == PEDONI_OK && hipMemsetAsync(ntile_weight, 0, n_tile_waves * sizeof(uint32_t), m->stream) != hipSuccess)
+        rc = fail(PEDONI_E_HIP, "ensure_capacity: hipMemsetAsync");
     if (per_agent_scan) {
         if (rc == PEDONI_OK) rc = grab(&nscan_in, nscan);
         if (rc == PEDONI_OK) rc = grab(&ncs0, nscan);
@@ -369,6 +381,10 @@ int ensure_capacity(PedoniModel* m, uint32_t need)
     hipFree(m->d_key); hipFree(m->d_slots);
     m->d_key = nkey;
     m->d_slots = nslots;
+    hipFree(m->d_tile_weight); hipFree(m->d_tile_order);
+    m->d_tile_weight = ntile_weight;
+    m->d_tile_order = ntile_order;
+    m->tile_order_blocks = 0;
     if (per_agent_scan) {
         hipFree(m->d_scan_in); hipFree(m->d_cs[0]); hipFree(m->d_block_sums);
         m->d_scan_in = nscan_in;
@@ -467,6 +483,17 @@ inline ForcePlan plan_force(const PedoniModel* m, uint32_t n, bool whole_array)
 // from ~3e5 agents on the SIMDs are busy and the group's redundant per-agent work costs more than
 // the shorter path brings.
 int group_by_size(uint32_t n) { return n < 40000u ? 4 : (n < 250000u ? 2 : 1); }
+
+// heaviest tiles first: only for the launch the order is built for -- every sorted agent of an unsharded model
+// through a one-lane-per-agent kernel in the XCD-contiguous order (a band's edge-first launch has an order of
+// its own; small crowds run the group kernel, whose launch is a single generation)
+bool tile_order_wanted(const PedoniModel* m, uint32_t n)
+{
+    if (!m->tile_order_on || !m->d_tile_order || !m->xcd_remap || m->halo_cap || m->force_simple || !m->opt.use_neighbor_grid || n == 0)
+        return false;
+    if (blocks_for(n, FORCE_THREADS) / 8u + 1u > TILE_CHUNK_MAX) return false;      // (more tiles per XCD than the builder holds)
+    return plan_force(m, n, true).group == 1;
+}
 
 } // namespace
 #ifdef PEDONI_DIAGNOSTICS
@@ -569,6 +596,14 @@ int sort_despawn(PedoniModel* m)
             uint32_t* const tickets = m->force_persist > 0 ? m->d_tickets : nullptr;
             uint32_t* const done_count = host_knows_general ? nullptr : m->d_tickets + 8 * TICKET_STRIDE;
             HaloIn* const consumed = (m->halo_cap || m->n_spawners) ? m->d_halo : nullptr;
+            // the workgroup order of the force launch this pass is followed by (whole-array launches of the
+            // one-lane kernels of an unsharded model: plan_force), built from the last launch's weights
+            TileOrder tiles{nullptr, nullptr, 0u};
+            m->tile_order_blocks = 0;
+            if (tile_order_wanted(m, n_total - m->base)) {
+                tiles = TileOrder{m->d_tile_weight, m->d_tile_order, blocks_for(n_total - m->base, FORCE_THREADS)};
+                m->tile_order_blocks = tiles.n_blocks;
+            }
 #ifdef PEDONI_DIAGNOSTICS
             // (the place kernel with parts switched off, and the dispatch-cost probes behind it: host_diag.hpp)
             if (m->place_ablate)
@@ -579,7 +614,7 @@ int sort_despawn(PedoniModel* m)
             hipLaunchKernelGGL(place_kernel, dim3(blocks_for(n_threads, bs)), dim3(bs), 0,
                                m->stream, m->d_key, i0, n_total, m->grid, band, m->d_cs[cs_old],
                                m->d_cs[cs_new], m->d_flags, parity, m->d_scan_in, soa, m->d_slots,
-                               consumed, m->d_row_count, row0, row1, m->d_live + 1, tickets, done_count);
+                               consumed, m->d_row_count, row0, row1, m->d_live + 1, tickets, done_count, tiles);
             m->tickets_fresh = true;
         }
         if (host_knows_general) {
@@ -703,6 +738,12 @@ int launch_force(PedoniModel* m, float2* acc_out, int part = 0, hipStream_t on =
             a.seg_row[1][0] = a.seg_row[1][1] = hi_a;
             a.clear_stale = 1;
         }
+    }
+    if (part == 0 && !acc_out && tile_order_wanted(m, n)) {
+        // (the order the sort pass built is this launch's if it was built for this grid; the weights this launch
+        // leaves are the next pass's input either way)
+        if (m->tile_order_blocks == blocks_for(n, FORCE_THREADS)) a.tile_order = m->d_tile_order;
+        a.tile_weight = m->d_tile_weight;
     }
     Timed t(m, on ? -1 : PEDONI_K_FORCE);   // the side-stream launch is not event-timed
     if (t.rc) return t.rc;
@@ -996,6 +1037,8 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
                 return fail(PEDONI_E_HIP, "create: trace buffer");
             }
         }
+        const char* nto = std::getenv("PEDONI_NO_TILE_ORDER");
+        m->tile_order_on = !(nto && nto[0] == '1');
         const char* ng = std::getenv("PEDONI_NO_GRAPH");
         m->use_graph = !(ng && ng[0] == '1');
         if (const char* fg = std::getenv("PEDONI_FORCE_GROUP")) {
@@ -1158,6 +1201,7 @@ void pedoni_hip_destroy(PedoniModel* m)
         hipFree(m->d_pos[k]); hipFree(m->d_velx[k]); hipFree(m->d_dest[k]);
     }
     hipFree(m->d_key); hipFree(m->d_slots);
+    hipFree(m->d_tile_weight); hipFree(m->d_tile_order);
     hipFree(m->d_scan_in); hipFree(m->d_cs[0]); hipFree(m->d_cs[1]); hipFree(m->d_block_sums);
     hipFree(m->d_skey[0]); hipFree(m->d_skey[1]); hipFree(m->d_flags);
     hipFree(m->d_live); hipFree(m->d_acc); hipFree(m->d_halo);
@@ -1604,6 +1648,26 @@ int pedoni_hip_cell_flags(PedoniModel* m, uint32_t* out, uint32_t cap, uint32_t*
     if (!out || !m->d_cell_flags) return PEDONI_OK;
     if (cap < m->n_cells) return fail(PEDONI_E_CAPACITY, "cell_flags: buffer too small");
     HIP_TRY(hipMemcpy(out, m->d_cell_flags, (size_t)m->n_cells * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PEDONI_OK;
+}
+
+int pedoni_hip_tile_order(PedoniModel* m, uint32_t* order, uint32_t* tile_weight, uint32_t cap, uint32_t* n_blocks)
+{
+    TRY(bind(m));
+    if (!n_blocks) return fail(PEDONI_E_INVALID, "tile_order: null n_blocks");
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    *n_blocks = m->tile_order_blocks;
+    if (!m->tile_order_blocks || (!order && !tile_weight)) return PEDONI_OK;
+    if (cap < m->tile_order_blocks) return fail(PEDONI_E_CAPACITY, "tile_order: buffer too small");
+    if (order) HIP_TRY(hipMemcpy(order, m->d_tile_order, (size_t)m->tile_order_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (tile_weight) {
+        std::vector<uint32_t> w((size_t)m->tile_order_blocks * FORCE_WAVES);
+        HIP_TRY(hipMemcpy(w.data(), m->d_tile_weight, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t t = 0; t < m->tile_order_blocks; ++t) {
+            tile_weight[t] = 0;
+            for (int k = 0; k < FORCE_WAVES; ++k) tile_weight[t] += w[(size_t)t * FORCE_WAVES + k];
+        }
+    }
     return PEDONI_OK;
 }
 

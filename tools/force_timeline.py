@@ -34,9 +34,19 @@ m.append(p, d, s0, v)
 m.sort_despawn()
 m.update_states(); m.sort_despawn()          # (one warm launch of the traced kernel)
 m.debug_force_trace(reset=True)
+order_used, weight_used = m.tile_order()      # the weights the order was built from (the launch before)
 m.update_states()
 n_waves = (len(p) + 63) // 64
+order, weight = m.tile_order()
+if len(order):
+    tot = weight.sum()
+    bucket = np.where(4.0 * weight * len(order) >= 7.0 * tot, 0, np.where(10.0 * weight * len(order) >= 13.0 * tot, 1, 2))
+    print(f"tile order in use: {len(order)} tiles, weights mean {weight.mean():.0f} p50 {np.percentile(weight, 50):.0f} p90 {np.percentile(weight, 90):.0f} "
+          f"p99 {np.percentile(weight, 99):.0f} max {weight.max()}; buckets (>= 1.75 mean / >= 1.3 mean / rest): {[int((bucket == k).sum()) for k in range(3)]}")
+else:
+    print("plain XCD-contiguous order (no tile order)")
 rec = m.debug_force_trace_raw(n_waves + 8)
+wave_id = np.flatnonzero(rec[:, 6] > 0)
 rec = rec[rec[:, 6] > 0]
 m.close()
 # rec[7]: start (low 40 bits) and duration (above) on the 100 MHz clock all XCDs share; rec[0..5]: shader cycles
@@ -80,3 +90,30 @@ print(f"  list schedule of the measured lifetimes on {slots} slots: in launch or
 names = ["prologue", "phase 1", "phase 2", "phase 3", "epilogue"]
 for label, sel in (("all waves", np.ones(len(life), bool)), ("heaviest 1 %", heavy), ("lightest 10 %", life <= np.percentile(life, 10))):
     print(f"  {label:14s}: " + ", ".join(f"{n} {us(rec[sel, k].mean()):.1f}" for k, n in enumerate(names)) + f"  (life {us(life[sel].mean()):.1f} us)")
+
+# the waves that end last: which tile, when they started, where their time went
+last = np.argsort(-end)[:12]
+print("  the 12 waves ending last (tile, tile weight, start us, life us, prologue / phase 1 / phase 2 / phase 3 / epilogue us):")
+for w in last:
+    t = int(wave_id[w]) // 4
+    tw = int(weight[t]) if len(order) else -1
+    print(f"    tile {t:5d} weight {tw:4d}  start {us(start[w]):6.1f}  life {us(life[w]):5.1f}   " + " / ".join(f"{us(rec[w, k]):.1f}" for k in range(5)))
+late = start >= np.percentile(start, 90)
+print(f"  waves dispatched in the last 10 %: lifetime mean {us(life[late].mean()):.1f} p90 {us(np.percentile(life[late], 90)):.1f} max {us(life[late].max()):.1f} us; "
+      + ", ".join(f"{n} {us(rec[late, k].mean()):.1f}" for k, n in enumerate(names)))
+
+if len(order):
+    # does the hardware start workgroups in the order asked for?  start time of XCD 0's i-th workgroup (b = 8 i)
+    tile_start = np.full(len(order), np.nan)
+    first_wave = wave_id % 4 == 0
+    tile_start[(wave_id[first_wave] // 4).astype(int)] = start[first_wave]
+    idx = [0, 1, 50, 100, 200, 220, 224, 230, 260, 300, 350, 400, 450, 480]
+    print("  XCD 0's i-th workgroup (hardware block 8 i): tile, weight, start us:")
+    print("   " + "  ".join(f"i={i}: t{int(order[8 * i])} w{int(weight[order[8 * i]])} {us(tile_start[order[8 * i]]):.1f}" for i in idx if 8 * i < len(order)))
+
+    if len(weight_used) == len(weight):
+        d = weight.astype(float) - weight_used.astype(float)
+        print(f"  weights the order was built from vs this launch's own: mean {weight_used.mean():.0f} -> {weight.mean():.0f}, |difference| mean {np.abs(d).mean():.1f} "
+              f"p99 {np.percentile(np.abs(d), 99):.0f} max {np.abs(d).max():.0f}; correlation {np.corrcoef(weight, weight_used)[0, 1]:.3f}")
+        for t in (3758, 3104, 503):
+            if t < len(weight): print(f"    tile {t}: used {int(weight_used[t])}, now {int(weight[t])}, started {us(tile_start[t]):.1f} us, position in its XCD's order {int(np.flatnonzero(order == t)[0]) // 8}")
