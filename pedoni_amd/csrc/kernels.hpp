@@ -80,8 +80,8 @@ __device__ __forceinline__ bool survives(const FieldView& f, v2 pos, uint32_t de
 //   bit m (m < 31): potential map m is >= 0.26 on every texel that util::bilinear can read for a
 //           position inside the 3 x 3 cells around c (an agent that ends its step outside that
 //           block, or with a NaN position, takes the sampled test);
-//   bit 31: on every texel the distance map's 3 x 3 Sobel taps + centre can read for a position inside
-//           c, the map lies in [21, 4096] AND steps by at least CELL_FLAG_STEP from texel to texel, with
+//   bit 31 (use_distance_map; the explicit-segment form: cell_flags_segments_kernel below): on every texel
+//           the distance map's 3 x 3 Sobel taps + centre can read for a position inside c, the map lies in [21, 4096] AND steps by at least CELL_FLAG_STEP from texel to texel, with
 //           one sign, along x or along y -- then the left and right (or upper and lower) tap columns
 //           differ by >= 8 steps in exact arithmetic against < 0.02 of accumulated fp32 rounding: the
 //           gradient cannot vanish, and every tap is finite.
@@ -156,6 +156,40 @@ __global__ void cell_flags_own_kernel(FieldView f, GridView g, uint32_t* __restr
         if (ok && (up_x || down_x || up_y || down_y)) bits |= CELL_FLAG_WALL;
     }
     own[c] = bits;
+}
+
+// bit 31 when the wall term comes from the explicit segments (use_distance_map = false, sfm.rs:193-236): every
+// obstacle adds normalize(nearest) * (2 * exp(-min_d / 0.2)) -- (+-0, +-0) once min_d > 20.8 m, and an obstacle
+// the agent is inside of adds nothing at all (:211-217).  The four segments of an obstacle (:200-209) all lie
+// within |width| / 2 of its centre line, so min_d >= distance(position, centre line) - |width| / 2: the bit is
+// set when that bound exceeds 21 m for EVERY obstacle from anywhere in the cell (distance from the cell's
+// centre minus its half diagonal).  A NaN in an obstacle clears it.  Replaces the distance-map bit 31 of
+// `own` (the two are never both in use).
+__global__ void cell_flags_segments_kernel(GridView g, const PedoniObstacle* __restrict__ obs, uint32_t n_obs, int32_t enable,
+                                           uint32_t* __restrict__ own)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (uint32_t)g.rows * (uint32_t)g.cols) return;
+    if (!enable) { own[c] &= ~CELL_FLAG_WALL; return; }        // (no claim about the segments: only the distance map's bit goes)
+    const int32_t cy = (int32_t)(c / (uint32_t)g.cols), cx = (int32_t)(c - (uint32_t)cy * (uint32_t)g.cols);
+    const double gu = (double)g.unit;
+    // the cell's extent in positions (cell 0 also holds (-gu, 0): `as i32` truncates towards zero), a little padded
+    const double x0 = (cx == 0 ? -gu : cx * gu) - 1e-3, x1 = (cx + 1.0) * gu + 1e-3;
+    const double y0 = (cy == 0 ? -gu : cy * gu) - 1e-3, y1 = (cy + 1.0) * gu + 1e-3;
+    const double mx = 0.5 * (x0 + x1), my = 0.5 * (y0 + y1);
+    const double reach = 0.5 * __builtin_sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0));
+    bool far = true;
+    for (uint32_t o = 0; o < n_obs && far; ++o) {
+        const double ax = obs[o].x0, ay = obs[o].y0, bx = (double)obs[o].x1 - ax, by = (double)obs[o].y1 - ay;
+        const double px = mx - ax, py = my - ay, bb = bx * bx + by * by;
+        double t = bb > 0.0 ? (px * bx + py * by) / bb : 0.0;
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        const double dx = px - t * bx, dy = py - t * by;
+        const double w = obs[o].width;
+        const double bound = __builtin_sqrt(dx * dx + dy * dy) - reach - 0.5 * (w < 0.0 ? -w : w);
+        far = bound > (double)CELL_FLAG_WALL_MIN;              // (false for NaN)
+    }
+    own[c] = (own[c] & ~CELL_FLAG_WALL) | (far ? CELL_FLAG_WALL : 0u);
 }
 
 // pass 2: a despawn bit holds for the whole 3 x 3 block the agent can end its step in
@@ -1284,7 +1318,11 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
         const bool wall_is_zero = (cflags & CELL_FLAG_WALL) != 0u && __builtin_fabsf(acc.x) > 0.0f && __builtin_fabsf(acc.y) > 0.0f;
         if (!wall_is_zero) acc = acc + obstacle_force_map<MODE>(a.field, pos, tab);
     }
-    else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
+    else {
+        // sfm.rs:193-236: `acc += force` once per obstacle; flagged cell: every one of those is (+-0, +-0) or skipped
+        const bool walls_are_zero = (cflags & CELL_FLAG_WALL) != 0u && __builtin_fabsf(acc.x) > 0.0f && __builtin_fabsf(acc.y) > 0.0f;
+        if (!walls_are_zero) obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
+    }
 
     if (a.acc_out) { a.acc_out[id] = make_float2(acc.x, acc.y); diag.flush(); on_exit(); return; }
 
@@ -1553,7 +1591,8 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
     if (a.key_next) dest_k = a.dest[id];
     const uint32_t cflags = cell_flags_of(a, ix, iy);             // (the despawn bits; the wall stencil ran beside the goal's)
     if (a.use_distance_map) acc = acc + wall;                     // (= obstacle_force_map: direction * k, lane 1's)
-    else obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);
+    else if (!((cflags & CELL_FLAG_WALL) != 0u && __builtin_fabsf(acc.x) > 0.0f && __builtin_fabsf(acc.y) > 0.0f))
+        obstacle_force_segments<MODE>(a.obstacles, a.n_obstacles, pos, acc, tab);   // (flagged cell: every term +-0, see force_queue_tile)
 
     if (a.acc_out) { if (writer) a.acc_out[id] = make_float2(acc.x, acc.y); diag.flush(); return; }
 

@@ -1156,6 +1156,11 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
             C_TRY(dev_alloc(&m->d_cell_flags, m->n_cells));
             C_TRY(dev_alloc(&own, m->n_cells));
             hipLaunchKernelGGL(cell_flags_own_kernel, dim3((m->n_cells + 255u) / 256u), dim3(256), 0, m->stream, m->field, m->grid, own);
+            // (wall segments instead of the distance map: bit 31 from the obstacles themselves -- unless the
+            // scenario has so many that the table would take seconds to build)
+            if (!opt->use_distance_map)
+                hipLaunchKernelGGL(cell_flags_segments_kernel, dim3((m->n_cells + 255u) / 256u), dim3(256), 0, m->stream, m->grid,
+                                   m->d_obstacles, n_obstacles, (double)m->n_cells * (double)n_obstacles <= 4.0e9 ? 1 : 0, own);
             hipLaunchKernelGGL(cell_flags_block_kernel, dim3((m->n_cells + 255u) / 256u), dim3(256), 0, m->stream, m->grid, own,
                                m->d_cell_flags);
             const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(m->stream);

@@ -231,3 +231,52 @@ def test_banded_model_clears_flags_outside_its_map_rows(hip, oracle):
     outside = ((cy + 1) * gu / fu + 4 < lo) | (cy * gu / fu - 4 >= hi)
     assert outside.sum() > 20 and not flags[outside].any()
     assert not (flags & ~want).any()          # never a claim the full model does not make
+
+
+def test_segment_walls_flag_means_every_obstacle_term_underflows(hip, oracle, monkeypatch):
+    """use_distance_map = false (sfm.rs:193-236): bit 31 claims that from anywhere in the cell every obstacle's
+    nearest segment is further than exp(-d / 0.2) can see.  Checked against the oracle's distance_from_line on
+    the cells' corners; then whole ticks with / without the table and against the oracle, bit for bit."""
+    sc = _hall_scenario()
+    field = oracle_field(oracle, sc)
+    m = _make_hip(hip, sc, field, use_distance_map=False)
+    flags = m.cell_flags()
+    wall = (flags & WALL) != 0
+    assert 0.25 < wall.mean() < 0.9
+    obstacles = sc.obstacle_array()
+    rng = np.random.default_rng(9)
+    ys, xs = np.nonzero(wall)
+    rim = np.zeros_like(wall)
+    rim[1:-1, 1:-1] = wall[1:-1, 1:-1] & ~(wall[:-2, 1:-1] & wall[2:, 1:-1] & wall[1:-1, :-2] & wall[1:-1, 2:])
+    pick = np.concatenate([np.flatnonzero(rim[ys, xs])[::3], rng.choice(len(ys), 300, replace=False)])
+    worst = np.inf
+    for i in pick:
+        px, py = _cell_positions(int(xs[i]), int(ys[i]), 1.4, rng, n_random=1)
+        for o in obstacles:
+            quad = oracle.line_with_width(o[:4].reshape(2, 2), float(o[4]))            # util.rs:106-111: l0-b, l0+b, l1+b, l1-b
+            segs = [(quad[0], quad[1]), (quad[3], quad[2]), (quad[1], quad[2]), (quad[0], quad[3])]   # the rectangle's 4 edges (sfm.rs:200-209)
+            for x, y in zip(px[::7], py[::7]):
+                d = min(float(np.hypot(*oracle.distance_from_line((x, y), np.array(sg)))) for sg in segs)
+                worst = min(worst, d)
+    assert worst > 20.8, f"a flagged cell is {worst:.2f} m from a wall segment"
+    k = oracle.expf_restated(np.array([-worst / 0.2], np.float32))
+    assert k[0] == 0.0
+
+    pos, dest, v0, vel = _crowd_with_goal_arrivals(field, sc.field.size, seed=21)
+    monkeypatch.setenv("PEDONI_NO_CELL_FLAGS", "1")
+    without = _make_hip(hip, sc, field, use_distance_map=False)
+    monkeypatch.delenv("PEDONI_NO_CELL_FLAGS")
+    cpu = oracle.OracleModel(sc.field.size, use_distance_map=False)
+    for g in (m, without):
+        g.append(pos, dest, v0, vel)
+        g.spawn_pedestrians()
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    for tick in range(4):
+        for g in (m, without):
+            g.update_states(); g.spawn_pedestrians()
+        cpu.update_states(field, obstacles); cpu.spawn_pedestrians(field)
+        for x, y, z in zip(m.download(), without.download(), cpu.download()):
+            same = lambda a, b: a.shape == b.shape and (bit_equal(a, b).all() if a.dtype == np.float32 else np.array_equal(a, b))
+            assert same(x, y), f"tick {tick}: the table changes a bit (segment walls)"
+            assert same(x, z), f"tick {tick}: differs from the oracle (segment walls)"
+    m.close(); without.close()
