@@ -234,13 +234,13 @@ def _by_age(path):
 
 
 def pmc_traffic(workload_key: str, kernel_symbol: str = ""):
-    """Fabric-side bytes per force-kernel launch from the newest committed rocprofv3 --pmc passes
-    (profiles/*pmc_force*.json, tools/pmc_summary.py) taken on THIS workload -- (dict, tag) or
-    (None, None).  `high` = 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction, calibrated
-    on 16 B / lane streams), `low` = FETCH_SIZE + WRITE_SIZE (no correction): this kernel's reads
-    are 4-16 B gathers, for which the correction was measured separately
-    (profiles/r03_gather_traffic.txt).  The counters sit at the TCC's fabric side: Infinity-Cache
-    hits are included, so this is not HBM bytes proper."""
+    """Bytes per force-kernel launch at the L2's fabric side, from the newest committed rocprofv3 --pmc passes
+    (profiles/*pmc_force*.json: tools/profile_traffic.sh, older ones tools/pmc_summary.py) taken on THIS workload
+    -- (dict, tag) or (None, None).  Reads are counted by request size: on gfx950 every fabric read request is
+    128 B (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ: profiles/r04_v2_traffic.txt, calibrated on streams and gathers of
+    known size), i.e. read bytes = 2 x FETCH_SIZE exactly -- the "1x" reading round 3 carried beside it is gone.
+    The counters sit at the TCC's fabric side: Infinity-Cache hits are included (not HBM bytes proper; the
+    requests cannot be told apart there)."""
     best = (None, None)
     for p in sorted((ROOT / "profiles").glob("*pmc_force*.json"), key=_by_age):      # rNN_vM names, oldest first
         try:
@@ -251,7 +251,18 @@ def pmc_traffic(workload_key: str, kernel_symbol: str = ""):
         # (profiles of round 1-2 carry no symbol: they are the one-lane kernel's)
         if _profile_workload(p.name) == workload_key and (not kernel_symbol or not sym or sym == kernel_symbol):
             fetch, write = (d.get("fetch_size_kb_raw") or 0.0) * 1024.0, (d.get("write_size_kb") or 0.0) * 1024.0
-            best = ({"high": 2.0 * fetch + write, "low": fetch + write}, p.name)
+            total = d.get("bytes_per_launch") or (2.0 * fetch + write)
+            parts = None
+            ab = d.get("ablation_read_bytes")
+            if ab and d.get("read_bytes"):
+                # where the reads come from: the diagnostics build's kernel with parts switched off
+                full, goal, wall, pairs = (ab.get(k) for k in ("nothing switched off", "no goal stencil", "no wall term", "no pair work (phases 1-3)"))
+                if full and goal and wall and pairs:
+                    parts = {"potential_map_goal_stencil": full - goal, "distance_map_wall_term": full - wall,
+                             "neighbour_gathers": full - pairs,
+                             "own_state_and_index": full - (full - goal) - (full - wall) - (full - pairs),
+                             "writes_state_keys_count_atomics": d.get("write_bytes")}
+            best = ({"total": total, "read": d.get("read_bytes") or 2.0 * fetch, "write": d.get("write_bytes") or write, "parts": parts}, p.name)
     return best
 
 
@@ -711,16 +722,17 @@ def main() -> None:
                 "bound": "valu" if valu and valu["frac"] > hbm_frac else "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": hbm_frac,
-                # bytes per launch seen by the TCC's fabric side in the committed --pmc profile of this
-                # workload, with the guide's 2x read correction (`traffic`) and without it
-                # (`traffic_low`): see pmc_traffic()
-                "traffic": traffic["high"] if traffic else None,
-                "traffic_low": traffic["low"] if traffic else None,
+                # bytes per launch at the TCC's fabric side in the committed --pmc profile of this workload and
+                # kernel (see pmc_traffic): one number -- read requests are counted by size -- with its parts
+                "traffic": traffic["total"] if traffic else None,
+                "traffic_read": traffic["read"] if traffic else None,
+                "traffic_write": traffic["write"] if traffic else None,
+                "traffic_parts": traffic["parts"] if traffic else None,
                 "traffic_profile": traffic_tag,
-                "traffic_note": ("from the committed rocprofv3 --pmc profile of this workload, not measured in this run; "
-                                 "fabric-side bytes, Infinity-Cache hits included (not HBM bytes proper); the 2x FETCH_SIZE read "
-                                 "correction is calibrated on 16 B/lane streams, this kernel's reads are 4-16 B gathers "
-                                 "(profiles/r03_gather_traffic.txt)") if traffic else None,
+                "traffic_note": ("from the committed rocprofv3 --pmc profile of this workload, not measured in this run; fabric-side "
+                                 "bytes, Infinity-Cache hits included (not HBM bytes proper); reads = 128 B x TCC_EA0_RDREQ (every read "
+                                 "request is 128 B on gfx950: profiles/r04_v2_traffic.txt); compulsory part beyond the algorithmic 40 B / "
+                                 "agent: the 64 MB potential map, which a crowd at 1 agent / m^2 touches in full each tick") if traffic else None,
                 "kernel": "force_integrate", "kernel_symbol": ksym, "avg_launch_ms": avg_ms,
                 "timed_launches": fk["launches"],
                 "algorithmic_bytes_per_launch": BYTES_FORCE * agents_local,

@@ -360,7 +360,12 @@ def test_bench_picks_the_newest_committed_profile():
         traffic, tag = bench.pmc_traffic(key)
         mine = [q for q in sorted(Path(bench.ROOT / "profiles").glob("*pmc_force*.json"), key=bench._by_age)
                 if bench._profile_workload(q.name) == key]
-        assert tag == mine[-1].name and traffic["high"] > traffic["low"] > 0
+        assert tag == mine[-1].name and traffic["total"] > traffic["read"] > 0 and traffic["write"] > 0
+        assert abs(traffic["total"] - traffic["read"] - traffic["write"]) < 1e-6 * traffic["total"]
+    # the C3 profile carries the request-size counters and the ablation passes: the line can say where the reads come from
+    c3, _ = bench.pmc_traffic("c3", "force_kernel_queue_s94<0, 6>")
+    assert c3["parts"] and c3["parts"]["potential_map_goal_stencil"] > c3["parts"]["neighbour_gathers"] > 0
+    assert 20e6 < c3["parts"]["own_state_and_index"] < 40e6          # ~24 B x 1e6 agents: the algorithmic reads, once
     for key in ("c3", "c4", "c4seg"):
         floor = bench.valu_floor(0.09, key, 1_000_000, "force_kernel_queue_s94<0, 6>")
         assert floor and bench._profile_workload(floor["profile"]) == key

@@ -40,8 +40,16 @@ def main():
         d["launches_seen"] = max(len(v) for v in cs.values())
         if dur.get(k):
             d["profiled_launch_us"] = sum(dur[k]) / len(dur[k]) / 1e3
-            if d.get("GRBM_GUI_ACTIVE"):      # rocprofv3 sums the 8 XCDs (MI355X_MICROARCH.md, DVFS)
+            # shader clock = GRBM_GUI_ACTIVE / 8 XCDs / duration (rocprofv3 sums the XCDs; MI355X_MICROARCH.md, DVFS) --
+            # only where the launch is long against what the counter also sees around it (its start-up and
+            # read-out: several us): for a 5-us scan the quotient came out at 5.7 "GHz".  Short kernels get the
+            # guide's nominal 2.4 GHz, and the file says which it is.
+            if d.get("GRBM_GUI_ACTIVE") and d["profiled_launch_us"] >= 50.0:
                 d["clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / (d["profiled_launch_us"] * 1e3)
+                d["clock_source"] = "GRBM_GUI_ACTIVE / 8 / profiled launch duration"
+            else:
+                d["clock_ghz"] = 2.4
+                d["clock_source"] = "nominal (launch shorter than 50 us: the counter quotient is not a clock)"
         wc = d.get("SQ_WAVE_CYCLES")
         if wc:
             for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
@@ -57,7 +65,7 @@ def main():
     p.write_text(json.dumps(res, indent=1, sort_keys=True))
     for k, d in res.items():
         if "force" in k:
-            print(k, json.dumps({c: (round(v, 4) if v < 10 else round(v)) for c, v in sorted(d.items())}, indent=1))
+            print(k, json.dumps({c: (v if isinstance(v, str) else (round(v, 4) if v < 10 else round(v))) for c, v in sorted(d.items())}, indent=1))
     print("wrote", p)
 
 
