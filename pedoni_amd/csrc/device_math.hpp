@@ -189,7 +189,11 @@ __device__ __forceinline__ int32_t f32_as_i32(float v)
 // ---- field sampling (util.rs:44-75, field.rs:235-258) -----------------------------
 struct FieldView {
     const float* distance_map;
-    const float* const* potential_maps; // device array of device pointers
+    // The potential maps live in ONE allocation, map m at pot_base + m * pot_stride: a map's address is
+    // arithmetic on the agent's destination, not a pointer fetched from memory -- one dependent round trip
+    // less at the head of every force-kernel wave (and the address is a global one to the compiler as it is).
+    const float* pot_base;
+    int64_t pot_stride;                 // floats from one map to the next
     int32_t rows, cols;
     float unit;
     uint32_t n_maps;
@@ -207,6 +211,11 @@ struct FieldView {
     uint32_t* status;
 };
 
+__device__ __forceinline__ const float* potential_map(const FieldView& f, uint32_t waypoint)
+{
+    return f.pot_base + (int64_t)waypoint * f.pot_stride;
+}
+
 // shape of one map as the sampling functions see it
 struct MapDims {
     int32_t rows, cols, y_lo, y_hi;
@@ -220,7 +229,7 @@ __device__ __forceinline__ MapDims dims_of(const FieldView& f)
 }
 constexpr uint32_t STATUS_FIELD_SLICE = 4u; // a texel outside the uploaded rows of the maps was asked for
 
-// A map pointer read from memory (potential_maps[dest]) is a FLAT pointer to the compiler: its
+// A map pointer that is not visibly derived from a kernel argument is a FLAT pointer to the compiler: its
 // loads would be flat_load_dword -- never merged into wider loads, and counted on the LDS counter
 // as well as the vector-memory one.  Every map lives in global memory: say so.
 typedef const __attribute__((address_space(1))) float* MapPtr;

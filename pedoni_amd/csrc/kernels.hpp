@@ -62,7 +62,7 @@ __device__ __forceinline__ bool survives(const FieldView& f, v2 pos, uint32_t de
 {
     if (dest >= f.n_maps) return false;
     v2 q = field_coord(f, pos);
-    return bilinear(f.potential_maps[dest], dims_of(f), q.x, q.y) > 0.25f;
+    return bilinear(potential_map(f, dest), dims_of(f), q.x, q.y) > 0.25f;
 }
 
 // ---- per-cell early-out flags (built once, at pedoni_hip_create) --------------------------------
@@ -121,7 +121,7 @@ __global__ void cell_flags_own_kernel(FieldView f, GridView g, uint32_t* __restr
     if ((int64_t)(x1 - x0 + 3) * (int64_t)(y1 - y0 + 3) > 4096) { own[c] = 0; return; }
     const uint32_t n_maps = f.n_maps < CELL_FLAG_MAPS ? f.n_maps : CELL_FLAG_MAPS;
     for (uint32_t m = 0; m < n_maps; ++m) {
-        MapPtr map = as_map(f.potential_maps[m]);
+        MapPtr map = as_map(potential_map(f, m));
         bool ok = true;
         for (int32_t y = y0; y <= y1 && ok; ++y) {
             if (y < 0 || y >= f.rows) continue;                       // out of shape: reads 1e12
@@ -931,7 +931,7 @@ __device__ __forceinline__ bool despawn_test_passes(const FieldView& f, uint32_t
     if (certain) return true;
     if (dest >= f.n_maps) return false;
     const v2 q = field_coord(f, pos);
-    return bilinear(f.potential_maps[dest], dims_of(f), q.x, q.y) > 0.25f;
+    return bilinear(potential_map(f, dest), dims_of(f), q.x, q.y) > 0.25f;
 }
 
 // goal force, sfm.rs:106-109
@@ -939,7 +939,7 @@ template <int MODE>
 __device__ __forceinline__ v2 goal_direction(const FieldView& f, v2 pos, uint32_t dest)
 {
     v2 q = field_coord(f, pos);
-    v2 g = sobel_fast(f.potential_maps[dest], dims_of(f), q.x, q.y, nullptr);
+    v2 g = sobel_fast(potential_map(f, dest), dims_of(f), q.x, q.y, nullptr);
     return normalize<0>(g); // exact in both math modes: `e` feeds the field-of-view decision
 }
 
@@ -1142,12 +1142,12 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
     bool ghost = false;
     int32_t ix = 0, iy = 0;   // the agent's cell (kept for the far-mover test of the tail)
     if (valid) {
-        float2 p = a.pos[id];
+        const float2 p = a.pos[id];
         vv = a.velx[id];
         pos = mk(p.x, p.y);
         vel = mk(vv.x, vv.y);
         desired_speed = vv.w;
-        uint32_t destination = a.dest[id];
+        const uint32_t destination = a.dest[id];
         ix = f32_as_i32(pos.x / a.grid.unit);                    // sfm.rs:113
         iy = f32_as_i32(pos.y / a.grid.unit);
         ghost = iy < a.band_lo || iy >= a.band_hi;
@@ -1470,7 +1470,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
             // handed round the group by DPP.  (The explicit-segment wall path stays in the epilogue.)
             const bool wall_lane = sub == 1 && a.use_distance_map;
             const float* map = wall_lane ? a.field.distance_map
-                                         : (destination < a.field.n_maps ? a.field.potential_maps[destination] : a.field.distance_map);
+                                         : (destination < a.field.n_maps ? potential_map(a.field, destination) : a.field.distance_map);
             const v2 q = field_coord(a.field, pos);
             float centre;
             const v2 g = sobel_fast(map, dims_of(a.field), q.x, q.y, &centre);

@@ -140,8 +140,7 @@ struct PedoniModel {
     // field (field.rs:194-205)
     FieldView field{};
     float* d_distance_map = nullptr;
-    std::vector<float*> d_pot;
-    const float** d_pot_ptrs = nullptr;
+    float* d_pot = nullptr;              // n_maps potential maps, one after the other
     PedoniObstacle* d_obstacles = nullptr;
     uint32_t n_obstacles = 0;
 
@@ -1093,19 +1092,15 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
     const size_t texels = (size_t)(map_row_end - map_row_begin) * field_cols;
     C_TRY(dev_alloc(&m->d_distance_map, texels));
     C_HIP(hipMemcpy(m->d_distance_map, distance_map + slice_off, texels * sizeof(float), hipMemcpyHostToDevice));
-    m->d_pot.resize(n_maps, nullptr);
-    std::vector<const float*> biased(n_maps, nullptr);
+    // (the potential maps in one allocation, map k at k * texels: device_math.hpp potential_map)
+    C_TRY(dev_alloc(&m->d_pot, (size_t)n_maps * texels));
     for (uint32_t k = 0; k < n_maps; ++k) {
         if (!potential_maps[k]) return bail(fail(PEDONI_E_INVALID, "create: null potential map"));
-        C_TRY(dev_alloc(&m->d_pot[k], texels));
-        C_HIP(hipMemcpy(m->d_pot[k], potential_maps[k] + slice_off, texels * sizeof(float), hipMemcpyHostToDevice));
-        biased[k] = (const float*)((uintptr_t)m->d_pot[k] - slice_off * sizeof(float));
+        C_HIP(hipMemcpy(m->d_pot + (size_t)k * texels, potential_maps[k] + slice_off, texels * sizeof(float), hipMemcpyHostToDevice));
     }
-    C_TRY(dev_alloc(&m->d_pot_ptrs, n_maps));
-    if (n_maps)
-        C_HIP(hipMemcpy(m->d_pot_ptrs, biased.data(), n_maps * sizeof(float*), hipMemcpyHostToDevice));
     m->field.distance_map = (const float*)((uintptr_t)m->d_distance_map - slice_off * sizeof(float));
-    m->field.potential_maps = m->d_pot_ptrs;
+    m->field.pot_base = (const float*)((uintptr_t)m->d_pot - slice_off * sizeof(float));
+    m->field.pot_stride = (int64_t)texels;
     m->field.y_lo = (int32_t)map_row_begin;
     m->field.y_hi = (int32_t)map_row_end;
     m->field.rows = (int32_t)field_rows;
@@ -1217,8 +1212,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     hipFree(m->d_trace);
     if (m->h_pinned) hipHostFree(m->h_pinned);
     hipFree(m->d_distance_map);
-    for (float* p : m->d_pot) hipFree(p);
-    hipFree((void*)m->d_pot_ptrs);
+    hipFree(m->d_pot);
     hipFree(m->d_obstacles);
     if (m->side_stream) { hipStreamSynchronize(m->side_stream); hipStreamDestroy(m->side_stream); }
     if (m->ev_sorted) hipEventDestroy(m->ev_sorted);
