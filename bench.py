@@ -651,13 +651,21 @@ def main() -> None:
     barrier()
     n_before = model.owned_count() if sharded else model.get_pedestrian_count()
     # inside the timed region the dominant kernel is event-timed on every `every`-th tick only
-    # (timed ticks launch eagerly inside one hipEvent pair, the others replay the captured tick
-    # pair): every 9th tick on long runs (an odd period: the 8 ticks between two timed ones replay
-    # as 4 pairs), every 3rd on the driver's short ones so that a 20-step run still times 7
-    # launches; the per-kernel pass after the timed region times 20 more, all kernels
-    every = 9 if args.steps >= 90 else 3
+    # (timed ticks launch eagerly inside one hipEvent pair, the others replay captured runs of
+    # ticks): every 17th / 9th tick on long runs (the 16 / 8 ticks between two timed ones replay as
+    # one graph launch); the driver's short runs time the first 7 ticks of the region (below);
+    # the per-kernel pass after the timed region times 20 more, all kernels
+    # (the library replays runs of up to 16 plain ticks from ONE captured graph -- the stream idles ~8 us between two
+    # graph launches -- so the period is one more than a run length it has: 17 or 9)
+    every = 17 if args.steps >= 170 else (9 if args.steps >= 90 else 3)
+    # short runs (the driver's 20 steps): the timed launches are the region's FIRST 7 ticks in a row, the rest of
+    # the region replays in long runs -- a timed tick between every two plain ones meant a graph launch (and its
+    # ~8 us of idle stream) per pair of ticks
+    burst = 7 if args.steps < 90 and args.steps >= 14 else 0
+    if burst:
+        every = max(args.steps, burst)
     if not args.no_profile:
-        model.profile(True, kernels=[abi.K_FORCE], every=every)
+        model.profile(True, kernels=[abi.K_FORCE], every=every, burst=burst)
         model.kernel_times(reset=True)
     stage("timed region", tick_bound(args.steps))
     barrier()
@@ -758,7 +766,7 @@ def main() -> None:
             fm.tick_n(crowd_age + args.warmup)
             fm.synchronize()
             nb = fm.get_pedestrian_count()
-            fm.profile(True, kernels=[abi.K_FORCE], every=every)
+            fm.profile(True, kernels=[abi.K_FORCE], every=every, burst=burst)
             fm.kernel_times(reset=True)
             t0 = time.perf_counter()
             fm.tick_n(args.steps)

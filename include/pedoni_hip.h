@@ -201,6 +201,11 @@ int pedoni_hip_profile(PedoniModel* m, int32_t kernel_mask);
 /* inside pedoni_hip_tick_n only every `every_ticks`-th tick is timed (default 1 = all): the
  * timed ticks launch eagerly, the others may replay the captured graph */
 int pedoni_hip_profile_every(PedoniModel* m, uint32_t every_ticks);
+/* [ext] ... or `burst_ticks` ticks in a row out of every `every_ticks`, the first burst starting with the next tick:
+ * the timed ticks launch eagerly, and the plain ticks between two bursts replay from captured graphs in runs of up to
+ * 16 ticks per graph launch -- a short timed region (bench.py's 20 steps) is then 7 timed ticks and two long runs
+ * instead of 7 timed ticks with a pair of plain ones between each two */
+int pedoni_hip_profile_burst(PedoniModel* m, uint32_t every_ticks, uint32_t burst_ticks);
 int pedoni_hip_kernel_times(PedoniModel* m, PedoniKernelTimes* out, int32_t reset);
 const char* pedoni_hip_kernel_name(int32_t k);
 

@@ -39,7 +39,7 @@ SYMBOLS = [
     "pedoni_hip_halo_tick_begin", "pedoni_hip_halo_tick_end",
     "pedoni_hip_owned_count",
     "pedoni_hip_selftest_math", "pedoni_hip_selftest_pair", "pedoni_hip_selftest_field", "pedoni_hip_set_spawners", "pedoni_hip_get_spawn_rng", "pedoni_hip_set_speed_rng",
-    "pedoni_hip_profile_every", "pedoni_hip_force_kernel_info",
+    "pedoni_hip_profile_every", "pedoni_hip_profile_burst", "pedoni_hip_force_kernel_info",
     "pedoni_hip_create_rows", "pedoni_shard_map_rows", "pedoni_hip_eikonal",
     "pedoni_shard_unique_id", "pedoni_shard_balanced_bounds", "pedoni_shard_recut_bounds", "pedoni_shard_create", "pedoni_shard_destroy",
     "pedoni_shard_begin", "pedoni_shard_tick_n", "pedoni_shard_owned_count", "pedoni_shard_band",
@@ -403,14 +403,18 @@ class HipModel:
     def synchronize(self) -> None:
         _check(self._lib, self._lib.pedoni_hip_synchronize(self._h))
 
-    def profile(self, enable, kernels: Optional[Sequence[int]] = None, every: int = 1) -> None:
+    def profile(self, enable, kernels: Optional[Sequence[int]] = None, every: int = 1, burst: int = 0) -> None:
         """Time kernel launches with hipEvent pairs: all kernels, or only the PEDONI_K_*
         indices in `kernels` (each pair costs a few microseconds on the stream); inside tick_n
-        only every `every`-th tick is timed (the others may replay the captured graph)."""
+        only every `every`-th tick is timed (the others may replay the captured graph) -- or, with
+        `burst`, that many ticks in a row out of every `every`, starting with the next tick."""
         mask = 0
         if enable:
             mask = 0xFF if kernels is None else sum(1 << k for k in kernels)
-        _check(self._lib, self._lib.pedoni_hip_profile_every(self._h, C.c_uint32(max(1, every))))
+        if burst:
+            _check(self._lib, self._lib.pedoni_hip_profile_burst(self._h, C.c_uint32(max(1, every)), C.c_uint32(burst)))
+        else:
+            _check(self._lib, self._lib.pedoni_hip_profile_every(self._h, C.c_uint32(max(1, every))))
         _check(self._lib, self._lib.pedoni_hip_profile(self._h, C.c_int32(mask)))
 
     def kernel_times(self, reset: bool = False) -> dict:

@@ -225,8 +225,16 @@ struct PedoniModel {
         uint32_t n_upper = 0, base = 0;
         int pv = 0, vd = 0, cs = 0, sk = 0;
         hipStream_t stream = nullptr;
-    } graphs[2];
-    void drop_graphs() { graphs[0].valid = graphs[1].valid = false; }
+    } graphs[2], long_graphs[3][2];
+    // ... and, per parity, runs of 16 / 8 / 4 ticks in ONE graph launch each: between two graph launches the stream
+    // idles ~8 us (tools/tick_timeline.sh) -- 4 us per tick with pairs, 0.5 with runs of 16.  A run is taken when that
+    // many ticks ahead are neither event-timed nor beyond the call (PEDONI_GRAPH_TICKS: longest run allowed, 0 = pairs only)
+    uint32_t graph_long = 16;
+    void drop_graphs()
+    {
+        graphs[0].valid = graphs[1].valid = false;
+        for (auto& lg : long_graphs) lg[0].valid = lg[1].valid = false;
+    }
     bool use_graph = true;     // PEDONI_NO_GRAPH=1: always launch eagerly
     // edge-first force launch of a band (launch_force part 3; set by the shard driver, shard.hpp)
     uint32_t* edge_counter = nullptr;   // device word
@@ -242,7 +250,10 @@ struct PedoniModel {
 
     // profiling
     uint32_t profile_mask = 0;
-    uint32_t profile_every = 1;   // tick_n: time the kernels of every n-th tick only
+    uint32_t profile_every = 1;   // tick_n: time the kernels of every n-th tick only ...
+    uint32_t profile_burst = 1;   // ... or of `burst` ticks in a row out of every n (pedoni_hip_profile_burst), counted from
+    uint64_t profile_phase = 0;   // this tick number
+    bool sampled(uint64_t t) const { return profile_mask != 0 && (t - profile_phase) % profile_every < profile_burst; }
     uint64_t tick_counter = 0;
     bool profile_now = true;      // false while tick_n runs a tick that is not sampled
     std::vector<EventPair> ev_pool;
@@ -1038,6 +1049,10 @@ int pedoni_hip_create_rows(const PedoniOptions* opt, float size_x, float size_y,
         }
         const char* nto = std::getenv("PEDONI_NO_TILE_ORDER");
         m->tile_order_on = !(nto && nto[0] == '1');
+        if (const char* gt = std::getenv("PEDONI_GRAPH_TICKS")) {
+            const int k = std::atoi(gt);
+            m->graph_long = k >= 16 ? 16u : (k >= 8 ? 8u : (k >= 4 ? 4u : 0u));
+        }
         const char* ng = std::getenv("PEDONI_NO_GRAPH");
         m->use_graph = !(ng && ng[0] == '1');
         if (const char* fg = std::getenv("PEDONI_FORCE_GROUP")) {
@@ -1219,6 +1234,7 @@ void pedoni_hip_destroy(PedoniModel* m)
     if (m->ev_interior) hipEventDestroy(m->ev_interior);
     for (hipEvent_t e : m->ev_tick) if (e) hipEventDestroy(e);
     for (auto& g : m->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
+    for (auto& lg : m->long_graphs) for (auto& g : lg) if (g.exec) hipGraphExecDestroy(g.exec);
     if (m->own_stream) hipStreamDestroy(m->own_stream);
     delete m;
 }
@@ -1405,6 +1421,34 @@ int tick_graph_pair(PedoniModel* m)
     m->sorted = false;
     return PEDONI_OK;
 }
+
+// a run of 16 / 8 / 4 ticks (which = 0 / 1 / 2; an even number: the host bookkeeping is back where it was) in one
+// graph launch; captured per parity the first time it is wanted
+constexpr uint32_t LONG_RUNS[3] = {16u, 8u, 4u};
+int tick_graph_long(PedoniModel* m, int which)
+{
+    PedoniModel::TickGraph& g = m->long_graphs[which][m->tick_parity & 1u];
+    if (!graph_matches(m, g)) {
+        const HostBook before = HostBook::of(m);
+        if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        g.valid = false;
+        const int rc = capture_ticks(m, (int)LONG_RUNS[which], &g);
+        if (rc != PEDONI_OK) {
+            before.restore(m);
+            m->drop_graphs();
+            m->use_graph = false;
+            return rc;
+        }
+    }
+    {
+        Range replay("run of ticks (captured graph replay)");
+        HIP_TRY(hipGraphLaunch(g.exec, m->stream));
+    }
+    m->keys_valid = true;
+    m->counts_dirty = true;
+    m->sorted = false;
+    return PEDONI_OK;
+}
 } // namespace
 
 int pedoni_hip_tick_n(PedoniModel* m, uint32_t steps)
@@ -1412,10 +1456,25 @@ int pedoni_hip_tick_n(PedoniModel* m, uint32_t steps)
     TRY(bind(m));
     // with profiling on, the kernels of every profile_every-th tick are event-timed (those
     // ticks launch eagerly); all other ticks may replay the captured pair
-    auto sampled = [&](uint64_t t) { return m->profile_mask != 0 && t % m->profile_every == 0; };
+    auto sampled = [&](uint64_t t) { return m->sampled(t); };
     uint32_t s = 0;
     int rc = PEDONI_OK;
     while (s < steps && rc == PEDONI_OK) {
+        if (m->graph_long && steps - s >= 4 && graphable(m)) {
+            // how many ticks ahead are plain ones (not event-timed, inside this call)?
+            uint32_t run = 0;
+            while (run < m->graph_long && run < steps - s && !sampled(m->tick_counter + run)) ++run;
+            int which = -1;
+            for (int k = 0; k < 3 && which < 0; ++k)
+                if (LONG_RUNS[k] <= run) which = k;
+            if (which >= 0) {
+                m->profile_now = false;
+                rc = tick_graph_long(m, which);
+                s += LONG_RUNS[which];
+                m->tick_counter += LONG_RUNS[which];
+                continue;
+            }
+        }
         if (steps - s >= 2 && !sampled(m->tick_counter) && !sampled(m->tick_counter + 1) && graphable(m)) {
             m->profile_now = false;
             rc = tick_graph_pair(m);
@@ -1735,6 +1794,19 @@ int pedoni_hip_profile_every(PedoniModel* m, uint32_t every_ticks)
     TRY(bind(m));
     if (every_ticks == 0) return fail(PEDONI_E_INVALID, "profile_every: must be >= 1");
     m->profile_every = every_ticks;
+    m->profile_burst = 1;
+    m->profile_phase = 0;
+    return PEDONI_OK;
+}
+
+int pedoni_hip_profile_burst(PedoniModel* m, uint32_t every_ticks, uint32_t burst_ticks)
+{
+    TRY(bind(m));
+    if (every_ticks == 0 || burst_ticks == 0 || burst_ticks > every_ticks)
+        return fail(PEDONI_E_INVALID, "profile_burst: need 1 <= burst <= every");
+    m->profile_every = every_ticks;
+    m->profile_burst = burst_ticks;
+    m->profile_phase = m->tick_counter;     // the next tick starts a burst
     return PEDONI_OK;
 }
 

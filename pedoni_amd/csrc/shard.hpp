@@ -372,7 +372,7 @@ struct SampledProfile {
     PedoniModel* m;
     explicit SampledProfile(PedoniModel* m_) : m(m_)
     {
-        m->profile_now = m->profile_mask != 0 && m->tick_counter % m->profile_every == 0;
+        m->profile_now = m->sampled(m->tick_counter);
         m->tick_counter += 1;
     }
     ~SampledProfile() { m->profile_now = true; }

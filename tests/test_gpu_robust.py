@@ -84,12 +84,12 @@ def test_graph_replay_equals_eager_launches(hip, oracle):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("every", [1, 2, 3, 5, 9])
+@pytest.mark.parametrize("every", [1, 2, 3, 5, 9, 17])
 def test_event_timed_ticks_between_replayed_pairs(hip, oracle, every):
     """bench.py times the force kernel on every n-th tick only (those launch eagerly, the others replay
-    the captured pair).  With n odd the pairs start on both halves of the ping-pong buffers: one
-    captured pair per half (both recorded at the first capture).  Same bits as plain eager launches,
-    and the timed launches are counted."""
+    captured runs of 16 / 8 / 4 / 2 ticks, whichever fits the stretch between two timed ticks and the end
+    of the call).  With n odd the runs start on both halves of the ping-pong buffers: one captured graph
+    per length and half.  Same bits as plain eager launches, and the timed launches are counted."""
     _, _, a, _ = _model(hip, oracle, n=30_000, L=130.0, seed=23)
     _, _, b, _ = _model(hip, oracle, n=30_000, L=130.0, seed=23)
     a.tick_n(4); a.synchronize()
@@ -97,13 +97,13 @@ def test_event_timed_ticks_between_replayed_pairs(hip, oracle, every):
         b.sort_despawn(); b.update_states()
     a.profile(True, kernels=[abi.K_FORCE], every=every)
     a.kernel_times(reset=True)
-    for steps in (20, 7):
+    for steps in (20, 7, 41):
         a.tick_n(steps)
         for _ in range(steps):
             b.sort_despawn(); b.update_states()
     times = a.kernel_times(reset=True)
     a.profile(False)
-    assert times["force_integrate"]["launches"] == len([t for t in range(4, 31) if t % every == 0])
+    assert times["force_integrate"]["launches"] == len([t for t in range(4, 72) if t % every == 0])
     a.tick_n(3)
     for _ in range(3):
         b.sort_despawn(); b.update_states()
