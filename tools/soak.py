@@ -1,6 +1,8 @@
 """One-off long soak (not part of the suite): N agents, T ticks free-running on the GPU, then a
 bitwise comparison with the oracle's own T ticks.
-    python tools/soak.py [N=200000] [T=3000] [segments]     (segments: use_distance_map = false)"""
+    python tools/soak.py [N=200000] [T=3000] [segments | hall | hall_segments]
+    (segments: use_distance_map = false; hall: a 700 m hall with 12 walls -- with N >= 4e5 the one-lane force kernel, the
+    wall early-out and the heaviest-first workgroup order all take part)"""
 import sys
 import time
 from pathlib import Path
@@ -15,8 +17,14 @@ from oracle import pyoracle as oracle         # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
-segments = len(sys.argv) > 3 and sys.argv[3] == "segments"
-sc = random_obstacle_scenario(360.0, 30 if segments else 700, seed=8)
+segments = len(sys.argv) > 3 and sys.argv[3] in ("segments", "hall_segments")
+hall = len(sys.argv) > 3 and sys.argv[3].startswith("hall")
+if hall:
+    # an open hall with a few walls: most cells are farther than 21 m from any wall (the wall early-out applies), the
+    # crowd is large enough for the one-lane force kernel and the heaviest-first workgroup order (>= 4e5 agents)
+    sc = random_obstacle_scenario(700.0, 12, seed=8)
+else:
+    sc = random_obstacle_scenario(360.0, 30 if segments else 700, seed=8)
 field = oracle_field(oracle, sc)
 pos, dest, v0, vel = inject_crowd(field, sc.field.size, n, 4, seed=13)
 cpu = oracle.OracleModel(sc.field.size, use_distance_map=not segments)
