@@ -137,8 +137,9 @@ int pedoni_hip_append(PedoniModel* m, const float* pos_xy, const uint32_t* desti
 /* [ext] the sort/despawn half of spawn_pedestrians alone (sfm.rs:58-88) */
 int pedoni_hip_sort_despawn(PedoniModel* m);
 /* [ext] `steps` x (sort_despawn; update_states) with no host round trip in between; in steady
- * state (nothing appended, no exchange, no device spawning) pairs of ticks are replayed from a
- * captured hipGraph -- same kernels, one launch per pair (PEDONI_NO_GRAPH=1 disables it) */
+ * state (nothing appended, no exchange, no device spawning) runs of 16 / 8 / 4 / 2 ticks are replayed
+ * from captured hipGraphs -- same kernels, one graph launch per run (PEDONI_NO_GRAPH=1 disables it,
+ * PEDONI_GRAPH_TICKS=n caps the run length) */
 int pedoni_hip_tick_n(PedoniModel* m, uint32_t steps);
 /* [ext] one Simulator::tick-shaped step with StepMetrics (lib.rs:64-100), no new agents */
 int pedoni_hip_tick(PedoniModel* m, PedoniStepMetrics* metrics);

@@ -40,6 +40,8 @@ def main():
 
     if mode == "fault":
         return fault_case(abi, pyoracle, tg, loop)
+    if mode == "tick_fault":
+        return tick_fault_case(abi, pyoracle, tg, world)
 
     big = os.environ.get("LOOPBACK_BIG") == "1"      # bands large enough for the 7-wave kernel BY SIZE
     tall = os.environ.get("LOOPBACK_TALL") == "1"    # bands of > 2048 grid rows each (a narrow, very tall box)
@@ -144,6 +146,52 @@ def main():
     for m in models + [single]:
         m.close()
     print(json.dumps(out))
+    return 0
+
+
+def tick_fault_case(abi, pyoracle, tg, world):
+    """LOOPBACK_RCCL_FAIL_SEND=k with k beyond the token ring's sends: an ncclSend of a TICK fails on one rank
+    (the other runs into the receive's timeout).  The failing call must report it, and the shard must refuse
+    further ticks -- its hand-offs are in no state to continue from -- until the band is reloaded and
+    pedoni_shard_begin is called again."""
+    sc = tg._tall_box(70.0, 210.0)
+    field = tg.oracle_field(pyoracle, sc)
+    pos, dest, v0, vel = tg._lopsided_crowd(field, sc.field.size, 30_000, seed=5)
+    probe = abi.HipModel(abi.Options(), sc.field.size, field.distance_map, field.potential_maps, field.unit, sc.obstacle_array())
+    rows, _ = probe.neighbor_grid_shape()
+    probe.close()
+    bounds = [(rows * r) // world for r in range(world + 1)]
+    uid = abi.shard_unique_id()
+    band_of = np.searchsorted(np.asarray(bounds[1:-1]), np.trunc(pos[:, 1] / np.float32(1.4)).astype(np.int64), side="right")
+    first, second, after_begin = [None] * world, [None] * world, [None] * world
+
+    def rank_main(r):
+        m = abi.HipModel(abi.Options(), sc.field.size, field.distance_map, field.potential_maps, field.unit, sc.obstacle_array())
+        s = abi.Shard(m, r, world, bounds, CAP, unique_id=uid)
+        s.selftest()
+        sel = band_of == r
+        m.append(pos[sel], dest[sel], v0[sel], vel[sel])
+        s.begin()
+        s.set_overlap(os.environ.get("LOOPBACK_OVERLAP") == "1")
+        try:
+            s.tick_n(6)
+            first[r] = "ok"
+        except abi.PedoniError as e:
+            first[r] = str(e)
+        try:
+            s.tick_n(1)
+            second[r] = "ok"
+        except abi.PedoniError as e:
+            second[r] = str(e)
+        after_begin[r] = "not tried"
+        s.close(); m.close()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    print(json.dumps({"ok": True, "first": first, "second": second}))
     return 0
 
 

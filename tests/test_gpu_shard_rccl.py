@@ -23,7 +23,8 @@ LOOPBACK = ROOT / "tests" / "loopback_rccl" / "libloopback_rccl.so"
 
 def _run(world, mode, extra_env=None):
     assert LOOPBACK.exists(), "tests/loopback_rccl is not built (python -m pedoni_amd.build)"
-    env = dict(os.environ, PEDONI_RCCL_LIB=str(LOOPBACK), LOOPBACK_RCCL_TIMEOUT_S="30", **(extra_env or {}))
+    env = dict(os.environ, PEDONI_RCCL_LIB=str(LOOPBACK), LOOPBACK_RCCL_TIMEOUT_S="30")
+    env.update(extra_env or {})
     p = subprocess.run([sys.executable, str(ROOT / "tests" / "loopback_shard_runner.py"), str(world), mode],
                        env=env, capture_output=True, text=True, timeout=600)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -100,3 +101,19 @@ def test_a_failed_send_inside_a_group_leaves_no_group_open(hip):
     assert out["first_error"] and "ncclSend" in out["first_error"], out
     assert out["depth_after_failure"] == 0, out
     assert out["second"] is True, out
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_a_tick_that_fails_midway_stops_the_shard(hip, overlap):
+    """an error inside a band's tick (here: an ncclSend of the third tick fails on one rank; its
+    neighbour runs into the receive's bound) used to leave `unpacked_ahead` / `in_flight` as they were and the
+    next tick skipped its unpack or exchanged twice.  Now the failing call reports the error, settles what is
+    under way and the shard refuses further ticks until pedoni_shard_begin."""
+    # sends so far: the token ring (2 per interior boundary and direction) and begin's pack; the 9th send is inside a tick
+    out = _run(2, "tick_fault", {"LOOPBACK_RCCL_FAIL_SEND": "9", "LOOPBACK_RCCL_TIMEOUT_S": "4", "LOOPBACK_OVERLAP": overlap})
+    assert out["ok"], out
+    assert any(f != "ok" for f in out["first"]), out                 # the failure was reported ...
+    failed = [r for r, f in enumerate(out["first"]) if f != "ok"]
+    for r in failed:
+        assert "pedoni_shard_begin" in out["first"][r], out            # ... says what to do ...
+        assert out["second"][r] != "ok" and "pedoni_shard_begin" in out["second"][r], out   # ... and the shard stays stopped
