@@ -326,13 +326,22 @@ __device__ __forceinline__ CellRanges old_ranges(const uint32_t* __restrict__ cs
 {
     CellRanges r;
     int32_t x0 = max(cx - 1, 0), x1 = min(cx + 1, g.cols - 1);
+    // all six words requested at once (a row outside the grid reads row cy's words instead and is emptied
+    // afterwards): a branch per row made three dependent round trips of them
+    uint32_t lo[3], hi[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        int32_t y = cy - 1 + k;
-        if (y < 0 || y >= g.rows) { r.lo[k] = r.hi[k] = 0; continue; }
-        int64_t off = (int64_t)y * g.cols;
-        r.lo[k] = cs_old[off + x0];
-        r.hi[k] = cs_old[off + x1 + 1];
+        const int32_t y = cy - 1 + k;
+        const int64_t off = (int64_t)((y < 0 || y >= g.rows) ? cy : y) * g.cols;
+        lo[k] = cs_old[off + x0];
+        hi[k] = cs_old[off + x1 + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int32_t y = cy - 1 + k;
+        const bool in = !(y < 0 || y >= g.rows);
+        r.lo[k] = in ? lo[k] : 0u;
+        r.hi[k] = in ? hi[k] : 0u;
     }
     return r;
 }
@@ -916,6 +925,28 @@ struct ForceArgs {
     int32_t ablate;            // diagnostics build only: SwitchDiag's bits (kernels_diag.hpp); no product kernel reads it
 };
 
+// sfm.rs:117-128: the agent's candidates are three contiguous index ranges, one per grid row iy-1 .. iy+1, columns
+// ix-1 .. ix+1 (clamped to the grid), walked in ascending row order.  All six words of neighbor_grid_indices are
+// requested at once: a row outside the grid reads row iy's words and is given length 0 (it keeps its place in
+// the order and contributes nothing) -- a loop over the rows that exist made dependent round trips of them.
+__device__ __forceinline__ void candidate_ranges(const ForceArgs& a, int32_t ix, int32_t iy, uint32_t& r0, uint32_t& n0,
+                                                 uint32_t& r1, uint32_t& n1, uint32_t& r2, uint32_t& n2)
+{
+    const int32_t x_start = max(ix - 1, 0), x_end = min(ix + 1, a.grid.cols - 1);     // :119-120
+    uint32_t lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int32_t y = iy - 1 + k;                                                  // :117-118
+        const int64_t offset = (int64_t)((y < 0 || y >= a.grid.rows) ? iy : y) * a.grid.cols;
+        lo[k] = a.cell_start[offset + x_start];
+        hi[k] = a.cell_start[offset + x_end + 1];
+    }
+    const bool in0 = iy - 1 >= 0, in2 = iy + 1 < a.grid.rows;
+    r0 = lo[0]; n0 = in0 ? hi[0] - lo[0] : 0u;
+    r1 = lo[1]; n1 = hi[1] - lo[1];
+    r2 = lo[2]; n2 = in2 ? hi[2] - lo[2] : 0u;
+}
+
 // the early-out flags of cell (ix, iy) -- the cell of a sorted agent, which the sort pass has checked
 __device__ __forceinline__ uint32_t cell_flags_of(const ForceArgs& a, int32_t ix, int32_t iy)
 {
@@ -1155,17 +1186,7 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
             if (diag.off(1)) e = mk(1.0f, 0.0f);
             else e = goal_direction<MODE>(a.field, pos, destination); // :107-108
             acc = acc + vdiv<MODE>(e * desired_speed - vel, 0.5f); // :109
-            int32_t y_start = max(iy - 1, 0), y_end = min(iy + 1, a.grid.rows - 1); // :117-118
-            int32_t x_start = max(ix - 1, 0), x_end = min(ix + 1, a.grid.cols - 1); // :119-120
-            // rows y_start..y_end in ascending order; a missing row contributes nothing
-            for (int32_t y = y_start, k = 0; y <= y_end; ++y, ++k) {
-                int64_t offset = (int64_t)y * a.grid.cols;
-                uint32_t i_start = a.cell_start[offset + x_start];
-                uint32_t i_end = a.cell_start[offset + x_end + 1];
-                if (k == 0) { r0 = i_start; n0 = i_end - i_start; }
-                else if (k == 1) { r1 = i_start; n1 = i_end - i_start; }
-                else { r2 = i_start; n2 = i_end - i_start; }
-            }
+            candidate_ranges(a, ix, iy, r0, n0, r1, n1, r2, n2);      // :117-120
         }
     }
     const uint32_t cnt = diag.off(4) ? 0u : n0 + n1 + n2;
@@ -1480,16 +1501,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
             e = mk(group_lane<G>(e_mine.x, 0), group_lane<G>(e_mine.y, 0));
             wall = mk(group_lane<G>(w_dir.x * w_k, 1), group_lane<G>(w_dir.y * w_k, 1));
             acc = acc + vdiv<MODE>(e * desired_speed - vel, 0.5f); // :109
-            int32_t y_start = max(iy - 1, 0), y_end = min(iy + 1, a.grid.rows - 1); // :117-118
-            int32_t x_start = max(ix - 1, 0), x_end = min(ix + 1, a.grid.cols - 1); // :119-120
-            for (int32_t y = y_start, k = 0; y <= y_end; ++y, ++k) {
-                int64_t offset = (int64_t)y * a.grid.cols;
-                uint32_t i_start = a.cell_start[offset + x_start];
-                uint32_t i_end = a.cell_start[offset + x_end + 1];
-                if (k == 0) { r0 = i_start; n0 = i_end - i_start; }
-                else if (k == 1) { r1 = i_start; n1 = i_end - i_start; }
-                else { r2 = i_start; n2 = i_end - i_start; }
-            }
+            candidate_ranges(a, ix, iy, r0, n0, r1, n1, r2, n2);      // :117-120
         }
     }
     const uint32_t cnt = n0 + n1 + n2;            // the agent's candidates: the same on all G lanes
