@@ -751,10 +751,19 @@ __device__ __forceinline__ void place_body(const uint32_t* __restrict__ key, uin
         if (!diag.off(4)) r = old_ranges(cs_old, grid, (int32_t)cx, (int32_t)cy);
         uint32_t before = 0;
         if (!diag.off(1)) {
+            // four keys per load instruction (the ranges are contiguous; a 16-byte global load needs 4-byte
+            // alignment only): the kernel is bound by its number of memory instructions, not by their latency
+            // (twelve scalar loads in flight at once, across the three ranges: place 18.3 -> 20.5 us)
+            typedef uint32_t key4 __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const uint32_t hi = min(r.hi[k], j);
-                for (uint32_t i = r.lo[k]; i < hi; ++i) before += key[i] == c ? 1u : 0u;
+                uint32_t i = r.lo[k];
+                for (; i + 4u <= hi; i += 4u) {
+                    const key4 q = *reinterpret_cast<const key4*>(key + i);
+                    before += (q.x == c ? 1u : 0u) + (q.y == c ? 1u : 0u) + (q.z == c ? 1u : 0u) + (q.w == c ? 1u : 0u);
+                }
+                for (; i < hi; ++i) before += key[i] == c ? 1u : 0u;
             }
         }
         const uint32_t to = diag.off(1) ? j : start + before;
