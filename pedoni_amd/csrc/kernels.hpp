@@ -1192,10 +1192,10 @@ __device__ __forceinline__ void force_queue_tile(const ForceArgs& a, const uint3
         iy = f32_as_i32(pos.y / a.grid.unit);
         ghost = iy < a.band_lo || iy >= a.band_hi;
         if (!ghost) {
+            candidate_ranges(a, ix, iy, r0, n0, r1, n1, r2, n2);      // :117-120 (requested ahead of the goal stencil's texels)
             if (diag.off(1)) e = mk(1.0f, 0.0f);
             else e = goal_direction<MODE>(a.field, pos, destination); // :107-108
             acc = acc + vdiv<MODE>(e * desired_speed - vel, 0.5f); // :109
-            candidate_ranges(a, ix, iy, r0, n0, r1, n1, r2, n2);      // :117-120
         }
     }
     const uint32_t cnt = diag.off(4) ? 0u : n0 + n1 + n2;
@@ -1498,6 +1498,7 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
             // :107-108) -- the same 4 x 4 patch code on a different map pointer, so the two stencils of
             // an agent run side by side instead of one after the other.  Both results are then
             // handed round the group by DPP.  (The explicit-segment wall path stays in the epilogue.)
+            candidate_ranges(a, ix, iy, r0, n0, r1, n1, r2, n2);      // :117-120 (requested ahead of the stencil's texels)
             const bool wall_lane = sub == 1 && a.use_distance_map;
             const float* map = wall_lane ? a.field.distance_map
                                          : (destination < a.field.n_maps ? potential_map(a.field, destination) : a.field.distance_map);
@@ -1510,7 +1511,6 @@ __device__ __forceinline__ void force_queue_tile_group(const ForceArgs& a, const
             e = mk(group_lane<G>(e_mine.x, 0), group_lane<G>(e_mine.y, 0));
             wall = mk(group_lane<G>(w_dir.x * w_k, 1), group_lane<G>(w_dir.y * w_k, 1));
             acc = acc + vdiv<MODE>(e * desired_speed - vel, 0.5f); // :109
-            candidate_ranges(a, ix, iy, r0, n0, r1, n1, r2, n2);      // :117-120
         }
     }
     const uint32_t cnt = n0 + n1 + n2;            // the agent's candidates: the same on all G lanes
