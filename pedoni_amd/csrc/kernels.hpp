@@ -531,8 +531,18 @@ scan_rows_kernel(uint32_t* __restrict__ cell_count, const uint32_t* __restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = first + k < cols ? count_load<WAIT>(in + first + k) : 0u;
     }
+    // the row totals before this row: four per thread requested at once (1024 rows a round; a loop of single
+    // loads made a dependent round trip of every 256 rows)
     uint32_t part = 0;
-    for (int32_t r = row0 + (int32_t)threadIdx.x; r < row; r += SCAN_THREADS) part += count_load<WAIT>(row_count + r);
+    for (int32_t r0 = row0 + (int32_t)threadIdx.x; r0 < row; r0 += 4 * SCAN_THREADS) {
+        uint32_t t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int32_t r = r0 + k * SCAN_THREADS;
+            t[k] = r < row ? count_load<WAIT>(row_count + r) : 0u;
+        }
+        part += (t[0] + t[1]) + (t[2] + t[3]);
+    }
     uint32_t before;
     block_exclusive_scan(part, lds, before);
     uint32_t carry = base + before;
