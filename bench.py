@@ -632,7 +632,11 @@ def main() -> None:
     # one would flatter the scaling curve.
     if crowd_age < SETTLE_TICKS:
         stage("settling the crowd", 60.0 + 0.05 * (SETTLE_TICKS - crowd_age) * max(1.0, n_per / 1e6))
-        step_fn(SETTLE_TICKS - crowd_age)
+        remaining = SETTLE_TICKS - crowd_age
+        # (the single-GPU tick replays captured runs of 16 / 8 / 4 / 2 ticks: settle in calls of every run length, so that
+        # every graph the timed region may want is captured and instantiated here, not there)
+        for chunk in ([16, 16, 8, 8, 4, 4, 2] if remaining == 58 and not sharded else [remaining]):
+            step_fn(chunk)
         crowd_age = SETTLE_TICKS
 
     def barrier():

@@ -1427,12 +1427,31 @@ int tick_graph_pair(PedoniModel* m)
 constexpr uint32_t LONG_RUNS[3] = {16u, 8u, 4u};
 int tick_graph_long(PedoniModel* m, int which)
 {
-    PedoniModel::TickGraph& g = m->long_graphs[which][m->tick_parity & 1u];
+    const uint32_t parity = m->tick_parity & 1u;
+    PedoniModel::TickGraph& g = m->long_graphs[which][parity];
     if (!graph_matches(m, g)) {
+        // this run's graph and, while we are at it, the one that starts on the other half of the ping-pong buffers
+        // (one discarded tick, the capture, one discarded tick -- as for the pairs): a caller that mixes single
+        // event-timed ticks in meets no capture + instantiate in mid-run (bench.py: all of them happen while
+        // the crowd settles, none inside the timed region).  A capture that fails puts the bookkeeping back.
         const HostBook before = HostBook::of(m);
-        if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-        g.valid = false;
-        const int rc = capture_ticks(m, (int)LONG_RUNS[which], &g);
+        auto captured = [&]() -> int {
+            if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+            g.valid = false;
+            TRY(capture_ticks(m, (int)LONG_RUNS[which], &g));
+            PedoniModel::TickGraph& o = m->long_graphs[which][parity ^ 1u];
+            if (!(o.valid && o.exec && o.n_upper == m->n_upper && o.base == m->base && o.stream == m->stream)) {
+                if (o.exec) { hipGraphExecDestroy(o.exec); o.exec = nullptr; }
+                o.valid = false;
+                TRY(capture_ticks(m, 1, nullptr));
+                TRY(capture_ticks(m, (int)LONG_RUNS[which], &o));
+                TRY(capture_ticks(m, 1, nullptr));
+                if ((m->tick_parity & 1u) != parity || !graph_matches(m, g))
+                    return fail(PEDONI_E_HIP, "tick graph: host state did not return after the second capture");
+            }
+            return PEDONI_OK;
+        };
+        const int rc = captured();
         if (rc != PEDONI_OK) {
             before.restore(m);
             m->drop_graphs();
