@@ -351,14 +351,20 @@ def _pair_fuzz_cases(rng, n):
     return pos, e, pos_i, vel
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_random_api_call_sequences_stay_in_lockstep(hip, oracle, seed):
+@pytest.mark.parametrize("seed,one_lane", [(1, False), (2, False), (3, False), (4, False), (5, True), (6, True)])
+def test_random_api_call_sequences_stay_in_lockstep(hip, oracle, monkeypatch, seed, one_lane):
     """The C-ABI is a small state machine (appended / sorted / updated; keys and per-cell counts
     fused into the previous update or not; gather or general sort form).  Random legal call
     sequences -- spawns of any size incl. none, repeated passes, single updates, un-synced
     batches, full-state appends, clears -- must keep the model bit-identical to the oracle
-    driven by the equivalent calls."""
-    sc = random_obstacle_scenario(70.0, 60, seed=seed)
+    driven by the equivalent calls.  `one_lane`: the one-lane-per-agent force kernel (what crowds of 4e5 agents
+    and more run), i.e. with the heaviest-first workgroup order rebuilt by every pass, in an open hall where the
+    wall early-out applies, and with un-synced batches long enough for the captured runs of 4 / 8 / 16 ticks."""
+    if one_lane:
+        monkeypatch.setenv("PEDONI_FORCE_GROUP", "1")
+        sc = random_obstacle_scenario(110.0, 4, seed=seed)
+    else:
+        sc = random_obstacle_scenario(70.0, 60, seed=seed)
     field = oracle_field(oracle, sc)
     rng = np.random.default_rng(100 + seed)
     cpu = oracle.OracleModel(sc.field.size, seed=77)
@@ -400,7 +406,7 @@ def test_random_api_call_sequences_stay_in_lockstep(hip, oracle, seed):
             gpu.update_states()
             is_sorted = False
         elif op == "tick_n":
-            k = int(rng.integers(1, 6))
+            k = int(rng.integers(1, 6)) if not one_lane else int(rng.choice([1, 2, 4, 5, 9, 17, 22]))
             gpu.tick_n(k)
             for _ in range(k):
                 cpu.spawn_pedestrians(field)
