@@ -280,3 +280,35 @@ def test_segment_walls_flag_means_every_obstacle_term_underflows(hip, oracle, mo
             assert same(x, y), f"tick {tick}: the table changes a bit (segment walls)"
             assert same(x, z), f"tick {tick}: differs from the oracle (segment walls)"
     m.close(); without.close()
+
+
+def test_more_waypoints_than_flag_bits(hip, oracle):
+    """The table has 31 despawn bits: agents heading for waypoint 31 and up always take the sampled test.
+    33 waypoints, agents for all of them, a few ticks through arrivals: bit-equal to the oracle."""
+    L = 90.0
+    sc = box_scenario(L)
+    sc.waypoints = [scn.SegmentConfig(((8.0 + 2.2 * k, 10.0), (8.0 + 2.2 * k, L - 10.0))) for k in range(33)]
+    field = oracle_field(oracle, sc)
+    assert len(field.potential_maps) == 33
+    rng = np.random.default_rng(4)
+    n = 6000
+    pos = np.stack([rng.uniform(6.0, L - 6.0, n), rng.uniform(6.0, L - 6.0, n)], 1).astype(np.float32)
+    dest = rng.integers(0, 33, n).astype(np.uint32)
+    dest[:600] = rng.integers(30, 33, 600)                    # plenty on both sides of the 31-bit line
+    v0 = np.clip(rng.normal(1.34, 0.26, n), 0.5, 2.2).astype(np.float32)
+    vel = np.zeros((n, 2), np.float32)
+    gpu = _make_hip(hip, sc, field)
+    flags = gpu.cell_flags()
+    assert ((flags >> np.uint32(30)) & 1).any()               # bit 30 is a despawn bit, bit 31 the wall bit
+    cpu = oracle.OracleModel(sc.field.size)
+    cpu.spawn_pedestrians(field, pos, dest, v0, vel)
+    gpu.append(pos, dest, v0, vel)
+    gpu.spawn_pedestrians()
+    n0 = cpu.get_pedestrian_count()
+    for _ in range(8):
+        cpu.update_states(field); gpu.update_states()
+        cpu.spawn_pedestrians(field); gpu.spawn_pedestrians()
+        for x, y in zip(gpu.download(), cpu.download()):
+            assert x.shape == y.shape and (bit_equal(x, y).all() if x.dtype == np.float32 else np.array_equal(x, y))
+    assert cpu.get_pedestrian_count() < n0, "some agents should have reached their waypoint"
+    gpu.close()
